@@ -1,0 +1,85 @@
+"""Shared parity cases: the configs the golden fixtures were generated with
+(tests/golden/make_golden.py) expressed for the oracle, plus seeded inputs."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from frankenstein_amd import synth
+from oracle import ref_models as R
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def state(shapes, seed=synth.SEED_WEIGHTS):
+    return {k: t(v) for k, v in synth.make_state(shapes, seed).items()}
+
+
+def enc_small():
+    return R.mae_config(window_size=32, n_electrodes=16, patch_size=4, dim=64, n_layers=2, head_dim=16,
+                        hidden_dim=128, n_heads=4, n_kv_heads=4)
+
+
+def bf_l1_small():
+    cfg = R.perceiver_config(enc_small(), n_output_tokens=8, output_dim=12, dim=64, n_layers=2, head_dim=8,
+                             hidden_dim=96, n_heads=4, n_kv_heads=4)
+    x = t(synth.make_inputs(3, 32, 16))
+    tgt = t(synth.make_motion_targets(3, 8, 12))
+    return cfg, x, tgt
+
+
+def bf_ce_small():
+    cfg = R.perceiver_config(enc_small(), n_output_tokens=7, output_dim=300, dim=64, n_layers=1, head_dim=16,
+                             hidden_dim=96, n_heads=4, n_kv_heads=4)
+    x = t(synth.make_inputs(3, 32, 16))
+    tok = t(synth.make_tokens(3, 7, vocab=300))
+    return cfg, x, tok
+
+
+def gpt_small(bias: bool):
+    cfg = R.gpt_config(block_size=64, vocab_size=211, n_layer=2, n_head=4, n_embd=64, dropout=0.0, bias=bias)
+    prefix = t(synth.make_motion_targets(3, 5, 64, seed=99))
+    tk = t(synth.make_tokens(3, 9, vocab=211))
+    idx = tk.clone()
+    idx[idx == -100] = 210
+    return cfg, prefix, tk, idx
+
+
+def cfg1():
+    enc = R.mae_config(window_size=200, n_electrodes=256, patch_size=25, dim=128, n_layers=2, head_dim=32,
+                       hidden_dim=512, n_heads=4, n_kv_heads=4)
+    bcfg = R.perceiver_config(enc, n_output_tokens=32, output_dim=128, dim=128, n_layers=2, head_dim=32,
+                              hidden_dim=256, n_heads=4, n_kv_heads=4)
+    gcfg = R.gpt_config(block_size=1024, vocab_size=50257, n_layer=2, n_head=4, n_embd=128, dropout=0.0, bias=True)
+    x = t(synth.make_inputs(4, 200, 256))
+    tok = t(synth.make_tokens(4, 25))
+    return bcfg, gcfg, x, tok
+
+
+def cfg1_shapes(bcfg, gcfg):
+    s = R.brainformer_shapes(bcfg, "to_words", p="brain_model.")
+    s.update(R.gpt_shapes(gcfg, p="llm_model."))
+    return s
+
+
+def cfg2(B=1, head_dim_out=128):
+    enc = R.mae_config(window_size=600, n_electrodes=256, patch_size=25, dim=384, n_layers=6, head_dim=64,
+                       hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    cfg = R.perceiver_config(enc, n_output_tokens=32, output_dim=head_dim_out, dim=384, n_layers=2, head_dim=64,
+                             hidden_dim=768, n_heads=6, n_kv_heads=6)
+    x = t(synth.make_inputs(B, 600, 256))
+    tgt = t(synth.make_motion_targets(B, 32, head_dim_out))
+    return cfg, x, tgt
+
+
+def summarize_rows(named):
+    names, rows = [], []
+    for k, v in named.items():
+        a = v.detach().double().flatten().numpy()
+        head = np.zeros(8)
+        head[: min(8, a.size)] = a[:8]
+        names.append(k)
+        rows.append(np.concatenate([[a.sum(), np.abs(a).sum()], head]))
+    return names, np.array(rows)

@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE (CPU, fp32).
+
+Runs only in the build container, where /root/reference is mounted read-only.  It imports the
+reference's own modules (models/brainformer.py, models/gpt2_model.py, utils/train_utils.py) and
+exec()s the notebook-only classes (BrainEncoder / Franky / CE-BrainFormer) straight from the
+.ipynb JSON — no reference source is copied into this repo; only inputs-by-seed and OUTPUT
+numbers are stored.  Harness-side stub modules stand in for the absent `simple_parsing` and
+`wandb` packages (they are only a dataclass base / a logger).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib.machinery
+import json
+import os
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+REF = Path(os.environ.get("FRANKEN_REFERENCE", "/root/reference"))
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.dont_write_bytecode = True
+
+from frankenstein_amd import synth  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- import the reference
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    class Serializable:  # dataclass base only (models/brainformer.py:11,18,40)
+        pass
+
+    class ArgumentParser:  # imported, never used (utils/train_utils.py:8)
+        pass
+
+    sp = _stub("simple_parsing", ArgumentParser=ArgumentParser)
+    sp.helpers = _stub("simple_parsing.helpers", Serializable=Serializable)
+    _stub("wandb", init=lambda *a, **k: None, log=lambda *a, **k: None)
+    sys.path.insert(0, str(REF))
+    import models.brainformer as bf  # type: ignore
+    import models.gpt2_model as g2  # type: ignore
+    import utils.train_utils as tu  # type: ignore
+    return bf, g2, tu
+
+
+def notebook_class(nb: str, cell: int, ns: dict):
+    d = json.load(open(REF / nb))
+    src = "".join(d["cells"][cell]["source"])
+    exec(compile(src, f"{nb}:cell{cell}", "exec"), ns)
+
+
+# ----------------------------------------------------------------------------- helpers
+def load_synth(model: torch.nn.Module, seed=synth.SEED_WEIGHTS, skip=("attn_mask",)):
+    sd = model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if v is not None}
+    st = synth.make_state(shapes, seed, skip)
+    # tied weights: lm_head.weight IS transformer.wte.weight -> one tensor, generated under the wte key
+    for k in list(st):
+        if k.endswith("lm_head.weight"):
+            st[k] = st[k.replace("lm_head.weight", "transformer.wte.weight")]
+    full = {k: torch.from_numpy(v) for k, v in st.items()}
+    missing, unexpected = model.load_state_dict(full, strict=False)
+    assert all(any(m.endswith(s) for s in skip) for m in missing), missing
+    assert not unexpected, unexpected
+    return shapes
+
+
+def summarize(named: dict):
+    """name -> [sum, abs-sum, first 8 values] float64 rows (tiny pins for big tensors)."""
+    names, rows = [], []
+    for k, t in named.items():
+        a = t.detach().double().flatten().numpy()
+        head = np.zeros(8)
+        head[: min(8, a.size)] = a[:8]
+        names.append(k)
+        rows.append(np.concatenate([[a.sum(), np.abs(a).sum()], head]))
+    return np.array(names), np.array(rows, dtype=np.float64)
+
+
+def grads_of(model):
+    seen, out = set(), {}
+    for k, p in model.named_parameters():
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        out[k] = p.grad if p.grad is not None else torch.zeros_like(p)
+    return out
+
+
+def params_of(model):
+    return {k: p for k, p in model.named_parameters()}
+
+
+def save(name, **arrs):
+    np.savez_compressed(OUT / f"{name}.npz", **arrs)
+    sz = (OUT / f"{name}.npz").stat().st_size
+    print(f"wrote {name}.npz  {sz/1024:.1f} KiB")
+
+
+def two_steps(model, loss_fn, tu, lrs=(1e-3, 5e-4), wd=1e-5, clip=1.0):
+    """Reference step body utils/train_utils.py:128-148 without accelerate: set lr, zero_grad, fwd, bwd,
+    clip_grad_value_, AdamW.step."""
+    opt = torch.optim.AdamW(model.parameters(), lr=lrs[0], weight_decay=wd)
+    losses = []
+    for lr in lrs:
+        for g in opt.param_groups:
+            g["lr"] = lr
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(model.parameters(), clip)
+        opt.step()
+        losses.append(float(loss))
+    return np.array(losses)
+
+
+# ----------------------------------------------------------------------------- cases
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    bf, g2, tu = import_reference()
+    from einops import rearrange
+    import torch.nn.functional as F
+    ns = dict(torch=torch, nn=torch.nn, F=F, rearrange=rearrange, Config=bf.Config, Encoder=bf.Encoder,
+              CrossBlock=bf.CrossBlock, build_complex_rope_cache=bf.build_complex_rope_cache)
+    notebook_class("notebooks_trainer/franky_baseline_gpt2.ipynb", 3, ns)   # BrainEncoder
+    notebook_class("notebooks_trainer/franky_baseline_gpt2.ipynb", 4, ns)   # Franky
+    BrainEncoder, Franky = ns["BrainEncoder"], ns["Franky"]
+    ns2 = dict(ns)
+    notebook_class("notebooks_trainer/train_brainformer.ipynb", 3, ns2)     # CE BrainFormer
+    BrainFormerCE = ns2["BrainFormer"]
+
+    # ---- ops: rope / mask / lr schedule / adamw
+    rng = np.random.default_rng(7)
+    xq = torch.from_numpy(rng.standard_normal((2, 10, 3, 8), dtype=np.float32))
+    cache = bf.build_complex_rope_cache(8, 16, 10000)
+    cache3 = cache[None, 3:13].repeat(2, 1, 1).clone()
+    cache3[1] = cache[None, 6:16]
+    sched = tu.init_lr_scheduler(tu.TrainConfig())
+    its = np.array([0, 1, 1000, 1999, 2000, 2001, 26000, 49999, 50000, 50001, 99999])
+    p0 = torch.from_numpy(rng.standard_normal(257, dtype=np.float32)).requires_grad_(True)
+    p_init = p0.detach().clone().numpy()
+    gs = [torch.from_numpy((3.0 * rng.standard_normal(257)).astype(np.float32)) for _ in range(3)]
+    opt = torch.optim.AdamW([p0], lr=1e-3, weight_decay=1e-5)
+    traj = []
+    for i, g in enumerate(gs):
+        for grp in opt.param_groups:
+            grp["lr"] = [1e-3, 7e-4, 2e-4][i]
+        p0.grad = g.clone()
+        torch.nn.utils.clip_grad_value_([p0], 1.0)
+        opt.step()
+        traj.append(p0.detach().clone().numpy())
+    save("ops",
+         rope_x=xq.numpy(), rope_out2d=bf.apply_rope(xq, cache).numpy(), rope_out3d=bf.apply_rope(xq, cache3).numpy(),
+         rope_cache_re=cache.real.numpy(), rope_cache_im=cache.imag.numpy(),
+         mask_12_4=bf.build_advanced_causal_mask(12, 4).numpy(),
+         lr_its=its, lr_vals=np.array([sched(int(i)) for i in its]),
+         adamw_p0=p_init, adamw_g=np.stack([g.numpy() for g in gs]), adamw_traj=np.stack(traj),
+         adamw_lrs=np.array([1e-3, 7e-4, 2e-4]))
+
+    # ---- bf_l1_small: file-class BrainFormer, h*dh != dim in the perceiver, odd sizes
+    enc = bf.MAEConfig(window_size=32, n_electrodes=16, patch_size=4, dim=64, n_layers=2, head_dim=16,
+                       hidden_dim=128, n_heads=4, n_kv_heads=4)
+    cfg = bf.Config(encoder=enc, n_output_tokens=8, output_dim=12, dim=64, n_layers=2, head_dim=8,
+                    hidden_dim=96, n_heads=4, n_kv_heads=4)
+    m = bf.BrainFormer(cfg).float()
+    load_synth(m)
+    x = torch.from_numpy(synth.make_inputs(3, 32, 16))
+    tgt = torch.from_numpy(synth.make_motion_targets(3, 8, 12))
+    loss, pred = m(x, tgt)
+    loss.backward()
+    ctx = m.encoder(x)
+    save("bf_l1_small", loss=np.array(float(loss)), pred=pred.detach().numpy(), enc_out=ctx.detach().numpy(),
+         **{"grad/" + k: v.numpy() for k, v in grads_of(m).items()})
+
+    # ---- bf_ce_small: notebook CE BrainFormer, V=300, targets with -100
+    cfg = bf.Config(encoder=enc, n_output_tokens=7, output_dim=300, dim=64, n_layers=1, head_dim=16,
+                    hidden_dim=96, n_heads=4, n_kv_heads=4)
+    m = BrainFormerCE(cfg).float()
+    load_synth(m)
+    tok = torch.from_numpy(synth.make_tokens(3, 7, vocab=300))
+    loss, logits = m(x, tok)
+    loss.backward()
+    save("bf_ce_small", loss=np.array(float(loss)), logits=logits.detach().numpy(), targets=tok.numpy(),
+         **{"grad/" + k: v.numpy() for k, v in grads_of(m).items()})
+
+    # ---- gpt_small: prefix forward, bias True / False, train + inference branch
+    for bias in (True, False):
+        gcfg = g2.GPTConfig(block_size=64, vocab_size=211, n_layer=2, n_head=4, n_embd=64, dropout=0.0, bias=bias)
+        g = g2.GPT(gcfg).float()
+        load_synth(g)
+        prefix = torch.from_numpy(synth.make_motion_targets(3, 5, 64, seed=99))
+        tk = torch.from_numpy(synth.make_tokens(3, 9, vocab=211))
+        idx = tk.clone()
+        idx[idx == -100] = 210
+        prefix.requires_grad_(True)
+        loss, logits = g(idx, prefix=prefix, targets=tk)
+        loss.backward()
+        _, last = g(idx, prefix=prefix.detach(), targets=None)
+        loss_np, logits_np = g(idx, prefix=None, targets=tk)
+        save(f"gpt_small_bias{int(bias)}", loss=np.array(float(loss)), logits=logits.detach().numpy(),
+             last_logits=last.detach().numpy(), targets=tk.numpy(), prefix_grad=prefix.grad.numpy(),
+             loss_noprefix=np.array(float(loss_np)), logits_noprefix=logits_np.detach().numpy(),
+             **{"grad/" + k: v.numpy() for k, v in grads_of(g).items()})
+
+    # ---- cfg1: Franky(BrainEncoder + gpt2-nano), B=4, T=200, + 2 optimizer steps
+    enc = bf.MAEConfig(window_size=200, n_electrodes=256, patch_size=25, dim=128, n_layers=2, head_dim=32,
+                       hidden_dim=512, n_heads=4, n_kv_heads=4)
+    bcfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=128, n_layers=2, head_dim=32,
+                     hidden_dim=256, n_heads=4, n_kv_heads=4)
+    gcfg = g2.GPTConfig(block_size=1024, vocab_size=50257, n_layer=2, n_head=4, n_embd=128, dropout=0.0, bias=True)
+    fr = Franky(BrainEncoder(bcfg), g2.GPT(gcfg)).float()
+    load_synth(fr)
+    x = torch.from_numpy(synth.make_inputs(4, 200, 256))
+    tok = torch.from_numpy(synth.make_tokens(4, 25))
+    feats = fr.brain_model(x)
+    loss, logits = fr(x, tok)
+    loss.backward()
+    gn, gr = summarize(grads_of(fr))
+    lg = logits.detach()
+    fr.zero_grad(set_to_none=True)
+    losses = two_steps(fr, lambda: fr(x, tok)[0], tu)
+    pn, pr = summarize(params_of(fr))
+    save("cfg1_franky", loss=np.array(float(loss)), features=feats.detach().numpy(),
+         logits_head=lg[:, :, :64].numpy(), logits_lse=torch.logsumexp(lg, -1).numpy(),
+         logits_argmax=lg.argmax(-1).numpy(), logits_tail=lg[:, :, -33:].numpy(),
+         grad_names=gn, grad_rows=gr, step_losses=losses, param_names=pn, param_rows=pr)
+
+    # ---- cfg2 at B=1: brainformer-small (6L, d=384, 6 heads x 64), N=6144 tokens, L1 head
+    enc = bf.MAEConfig(window_size=600, n_electrodes=256, patch_size=25, dim=384, n_layers=6, head_dim=64,
+                       hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=384, n_layers=2, head_dim=64,
+                    hidden_dim=768, n_heads=6, n_kv_heads=6)
+    m = bf.BrainFormer(cfg).float()
+    load_synth(m)
+    x = torch.from_numpy(synth.make_inputs(1, 600, 256))
+    tgt = torch.from_numpy(synth.make_motion_targets(1, 32, 128))
+    loss, pred = m(x, tgt)
+    loss.backward()
+    with torch.no_grad():
+        ctx = m.encoder(x)
+    gn, gr = summarize(grads_of(m))
+    save("cfg2_b1", loss=np.array(float(loss)), pred=pred.detach().numpy(),
+         enc_rows=ctx[0, [0, 1, 255, 256, 3071, 6143]].numpy(), grad_names=gn, grad_rows=gr)
+
+
+if __name__ == "__main__":
+    main()
