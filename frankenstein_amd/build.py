@@ -1,0 +1,61 @@
+"""Build libfranken_hip.so (gfx950 only) in-tree with hipcc.  `python -m frankenstein_amd.build`."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+LIB = HERE / "libfranken_hip.so"
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_optim.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    hdrs = [CSRC / "fk_common.h", HERE.parent / "include" / "franken_hip.h"]
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        o = objdir / (src + ".o")
+        if force or _stale(o, [CSRC / src, *hdrs]):
+            jobs.append((src, o))
+
+    def cc(job):
+        src, o = job
+        cmd = [HIPCC, *FLAGS, "-c", str(CSRC / src), "-o", str(o)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip() and verbose:
+            print(r.stderr, file=sys.stderr)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(cc, jobs))
+    objs = [objdir / (s + ".o") for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

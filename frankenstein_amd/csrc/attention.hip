@@ -1,0 +1,675 @@
+// attention.hip — flash-style fused attention forward / backward for gfx950.
+//
+// Replaces F.scaled_dot_product_attention at models/brainformer.py:168 (self, bool block-causal mask),
+// :215 (cross, no mask) and models/gpt2_model.py:64 (is_causal) of the reference.  The [N,N] boolean
+// mask of models/brainformer.py:93-111 is never materialised: it is the analytic predicate
+// (k + k_off) / C <= (q + q_off) / C, evaluated per tile (and per element only on boundary tiles).
+//
+// Layout: Q/K/V/O are [B, N, H, D] views (row stride and batch stride in elements, head h at column
+// h*D) — exactly what the QKV projection GEMM writes, so there is no transpose pass.
+//
+// Orientation ("query on the lane"): S^T = K Q^T, so a lane owns one query column; row max / row sum /
+// rescale are per-lane scalars (one cross-half shuffle), and the S^T accumulator registers are directly
+// the B operand of O^T += V^T P^T (fk_common.h: acc_row_of_slot).  K is read from LDS row-wise
+// (ds_read_b128), V through the transposed read (ds_read_b64_tr_b16) for bf16.
+// Backward = two kernels (no atomics, deterministic):
+//   dkdv: one workgroup per 128 keys, wave = 32 keys ("key on the lane"): S = Q K^T, dP = dO V^T,
+//         dV^T += dO^T P, dK^T += Q^T dS, sweeping the visible query tiles;
+//   dq  : forward-shaped: S^T, dP^T = V dO^T, dQ^T += K^T dS^T.
+// P is recomputed from the saved log-sum-exp; delta = rowsum(dO * O) comes from a small pre-pass.
+// fp32 variants (exact-fp32 MFMA) exist for the parity mode.
+#include "fk_common.h"
+
+namespace {
+
+constexpr int NT = 256;     // threads per workgroup (4 waves)
+constexpr int BQ = 128;     // query rows per workgroup (fwd, dq): 32 per wave
+constexpr int BKV = 64;     // keys per staged tile (fwd, dq)
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnArgs {
+  const void *Q, *K, *V, *O, *dO;
+  void *Out, *dQ, *dK, *dV;
+  float *LSE, *delta;
+  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  int B, H, Nq, Nk;
+  int mask_kind, mask_c, q_off, k_off;
+  float scale;
+};
+
+template <typename T, int D> struct AT {
+  static constexpr int ES = sizeof(T);
+  static constexpr int RB = D * ES;                 // bytes per head row
+  static constexpr int CPR = RB / 16;               // 16-byte chunks per row
+  static constexpr int KSTEPS = D / 16;             // k16 steps across the head dim
+  static constexpr int DT = (D + 31) / 32;          // 32-row tiles of O^T / dK^T / dV^T
+  static constexpr int DPAD = DT * 32;
+  static constexpr int RSTRIDE = DPAD * ES + 16;    // row-read / dual-use LDS image stride (padded: conflict-free b128)
+  static constexpr int VRB = DPAD * ES;
+  static constexpr int VSTRIDE = (ES == 2) ? ((((VRB / 64) & 1) != 0) ? VRB : VRB + 64) : VRB + 16;  // tr-only image
+  static constexpr int VEC = 16 / ES;
+};
+
+FK_DEV bool visible(int kind, int c, int qpos, int kpos) {
+  if (kind == FK_MASK_CAUSAL) return kpos <= qpos;
+  if (kind == FK_MASK_BLOCK_CAUSAL) return (kpos / c) <= (qpos / c);
+  return true;
+}
+// exclusive upper bound of key INDICES visible to query index q (monotone predicates only)
+FK_DEV int kv_limit(const AttnArgs& p, int q) {
+  const int qpos = q + p.q_off;
+  if (p.mask_kind == FK_MASK_CAUSAL) return min(p.Nk, max(0, qpos - p.k_off + 1));
+  if (p.mask_kind == FK_MASK_BLOCK_CAUSAL) return min(p.Nk, max(0, (qpos / p.mask_c + 1) * p.mask_c - p.k_off));
+  return p.Nk;
+}
+// smallest query INDEX that can see key index k
+FK_DEV int q_first(const AttnArgs& p, int k) {
+  const int kpos = k + p.k_off;
+  if (p.mask_kind == FK_MASK_CAUSAL) return max(0, kpos - p.q_off);
+  if (p.mask_kind == FK_MASK_BLOCK_CAUSAL) return max(0, (kpos / p.mask_c) * p.mask_c - p.q_off);
+  return 0;
+}
+
+// ---- LDS fragment reads -------------------------------------------------------------------------
+// row-read: 8 contiguous head-dim elements (slots d = 16 s + 8 h + e) of image row `row`
+template <typename T> FK_DEV void frag_row(Frag<T>& f, const char* img, int stride, int row, int s, int h) {
+  frag_load_contig<T>(f, reinterpret_cast<const T*>(img + row * stride) + 16 * s + 8 * h);
+}
+// transposed read paired with an accumulator-as-B operand: output row = image column cb + (lane & 31),
+// slot (h, e) = image row  rb + 16 s + 8 (e >> 2) + 4 h + (e & 3)
+template <typename T> FK_DEV void frag_tr(Frag<T>& f, const char* img, int stride, int rb, int s, int cb, int lane);
+template <> FK_DEV void frag_tr<bf16_t>(Frag<bf16_t>& f, const char* img, int stride, int rb, int s, int cb, int lane) {
+  const int g = lane >> 4, i = lane & 15, h = g >> 1;
+  const int col = cb + 16 * (g & 1) + 4 * (i & 3);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = rb + 16 * s + 8 * t + 4 * h + (i >> 2);
+    bf16x4 v = lds_read_tr4(reinterpret_cast<const bf16_t*>(img + row * stride) + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f.v[4 * t + e] = v[e];
+  }
+}
+template <> FK_DEV void frag_tr<float>(Frag<float>& f, const char* img, int stride, int rb, int s, int cb, int lane) {
+  const int h = lane >> 5, c = cb + (lane & 31);
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    f.v[e] = reinterpret_cast<const float*>(img + (rb + acc_row_of_slot(s, h, e)) * stride)[c];
+}
+
+// ---- global -> register -> LDS staging of a [ROWS][D] head tile -----------------------------------
+template <typename T, int D, int ROWS> struct Stager {
+  using C = AT<T, D>;
+  static constexpr int TOTAL = ROWS * C::CPR;
+  static constexpr int NCH = (TOTAL + NT - 1) / NT;
+  u32x4 r[NCH];
+  FK_DEV void load(const T* base, int64_t rs, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + NT * i, row = id / C::CPR, ch = id % C::CPR;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      r[i] = (id < TOTAL && row0 + row < nrows)
+                 ? *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + row) * rs + ch * C::VEC) : z;
+    }
+  }
+  FK_DEV void store(char* img, int stride, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + NT * i, row = id / C::CPR, ch = id % C::CPR;
+      if (id < TOTAL) *reinterpret_cast<u32x4*>(img + row * stride + ch * 16) = r[i];
+    }
+  }
+};
+
+template <int N> FK_DEV void zero_acc(f32x16 (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[i][r] = 0.0f;
+}
+
+// store a [d x q] accumulator set (lane = q row, registers = d) as rows of a [.., H, D] matrix
+template <typename T, int D>
+FK_DEV void store_rows_T(T* base, int64_t rs, int row, bool row_ok, const f32x16 (&acc)[AT<T, D>::DT], float mul, int lh) {
+  if (!row_ok) return;
+#pragma unroll
+  for (int dt = 0; dt < AT<T, D>::DT; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = dt * 32 + 8 * g + 4 * lh;
+      if (d < D) {
+        T* dst = base + (int64_t)row * rs + d;
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(acc[dt][4 * g + j] * mul);
+          *reinterpret_cast<bf16x4*>(dst) = v;
+        } else {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[dt][4 * g + j] * mul;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
+      }
+    }
+}
+
+// ================================================================================================= forward
+template <typename T, int D>
+__global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
+  using C = AT<T, D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KIMG = BKV * C::RSTRIDE, VIMG = BKV * C::VSTRIDE;
+  auto kimg = [&](int i) -> char* { return smem + i * KIMG; };
+  auto vimg = [&](int i) -> char* { return smem + 2 * KIMG + i * VIMG; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * BQ;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const int qrow = q0 + wave * 32 + li;
+  const bool q_ok = qrow < p.Nq;
+
+  if constexpr (C::DPAD != D) {   // zero the padded columns of the V images once (never restaged)
+    for (int i = tid; i < 2 * VIMG / 4; i += NT) reinterpret_cast<float*>(vimg(0))[i] = 0.0f;
+    __syncthreads();
+  }
+
+  Frag<T> qf[C::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s) {
+    if (q_ok) frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+    else frag_zero<T>(qf[s]);
+  }
+
+  const int q_last = min(q0 + BQ, p.Nq) - 1;
+  const int kv_end = kv_limit(p, q_last);
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+  // first key index that is NOT visible to every query row of this wave (tiles below need no mask test)
+  const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
+  const int full_vis_end = kv_limit(p, wave_q_first);
+
+  Stager<T, D, BKV> sk, sv;
+  if (ntiles > 0) {
+    sk.load(Kp, p.k_rs, 0, p.Nk, tid);
+    sv.load(Vp, p.v_rs, 0, p.Nk, tid);
+    sk.store(kimg(0), C::RSTRIDE, tid);
+    sv.store(vimg(0), C::VSTRIDE, tid);
+  }
+  __syncthreads();
+
+  const float c = p.scale * LOG2E;
+  float m = -INFINITY, l = 0.0f;
+  f32x16 o[C::DT];
+  zero_acc(o);
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kb = t * BKV;
+    if (t + 1 < ntiles) {
+      sk.load(Kp, p.k_rs, kb + BKV, p.Nk, tid);
+      sv.load(Vp, p.v_rs, kb + BKV, p.Nk, tid);
+    }
+    const char* kt = kimg(t & 1);
+    const char* vt = vimg(t & 1);
+    f32x16 sc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[u][r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < C::KSTEPS; ++s) {
+        Frag<T> kf;
+        frag_row<T>(kf, kt, C::RSTRIDE, 32 * u + li, s, lh);
+        mma32<T>(sc[u], kf, qf[s]);
+      }
+    }
+    if (kb + BKV > full_vis_end) {   // wave-uniform: boundary tile -> per-element predicate
+      const int qpos = qrow + p.q_off;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb + 32 * u + acc_row(r, lh);
+          if (!(key < p.Nk && visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))) sc[u][r] = -INFINITY;
+        }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[u][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m - m_new) * c);
+    const float mc = (m_new == -INFINITY) ? 0.0f : m_new * c;
+    m = m_new;
+    float rs = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(sc[u][r] * c - mc);
+        sc[u][r] = pv;
+        rs += pv;
+      }
+    l = l * alpha + rs;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag<T> pf;
+        frag_from_acc<T>(pf, sc[u], s);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+          Frag<T> vf;
+          frag_tr<T>(vf, vt, C::VSTRIDE, 32 * u, s, 32 * dt, lane);
+          mma32<T>(o[dt], vf, pf);
+        }
+      }
+    if (t + 1 < ntiles) {
+      sk.store(kimg((t + 1) & 1), C::RSTRIDE, tid);
+      sv.store(vimg((t + 1) & 1), C::VSTRIDE, tid);
+    }
+    __syncthreads();
+  }
+
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;   // fully masked row -> 0 (torch >= 2.1 CPU semantics)
+  T* Op = (T*)p.Out + (int64_t)b * p.o_bs + hd * D;
+  store_rows_T<T, D>(Op, p.o_rs, qrow, q_ok, o, inv, lh);
+  if (q_ok && lh == 0 && p.LSE)
+    p.LSE[((int64_t)b * p.H + hd) * p.Nq + qrow] = lt > 0.0f ? m * p.scale + logf(lt) : INFINITY;
+}
+
+// ================================================================================================= delta
+template <typename T, int D>
+__global__ void attn_delta_kernel(AttnArgs p) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.H * p.Nq;
+  if (idx >= total) return;
+  const int q = (int)(idx % p.Nq), hd = (int)((idx / p.Nq) % p.H), b = (int)(idx / ((int64_t)p.Nq * p.H));
+  const T* o = (const T*)p.O + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + hd * D;
+  const T* g = (const T*)p.dO + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + hd * D;
+  float s = 0.0f;
+  constexpr int VEC = 16 / sizeof(T);
+#pragma unroll
+  for (int i = 0; i < D / VEC; ++i) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(o + i * 8), c = *reinterpret_cast<const bf16x8*>(g + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
+    } else {
+      f32x4 a = *reinterpret_cast<const f32x4*>(o + i * 4), c = *reinterpret_cast<const f32x4*>(g + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += a[e] * c[e];
+    }
+  }
+  p.delta[idx] = s;   // [B, H, Nq]
+}
+
+// ================================================================================================= dQ
+template <typename T, int D>
+__global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
+  using C = AT<T, D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = BKV * C::RSTRIDE;
+  auto kimg = [&](int i) -> char* { return smem + i * IMG; };
+  auto vimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * BQ;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const int qrow = q0 + wave * 32 + li;
+  const bool q_ok = qrow < p.Nq;
+
+  if constexpr (C::DPAD != D) {   // padded columns feed the transposed K reads: keep them zero
+    for (int i = tid; i < 4 * IMG / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
+    __syncthreads();
+  }
+
+  Frag<T> qf[C::KSTEPS], gf[C::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s) {
+    if (q_ok) {
+      frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+      frag_load_contig<T>(gf[s], Gp + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
+    } else {
+      frag_zero<T>(qf[s]);
+      frag_zero<T>(gf[s]);
+    }
+  }
+  const int64_t stat = ((int64_t)b * p.H + hd) * p.Nq + qrow;
+  const float lse2 = q_ok ? p.LSE[stat] * LOG2E : INFINITY;   // +inf -> P = 0 for padded rows
+  const float dl = q_ok ? p.delta[stat] : 0.0f;
+
+  const int q_last = min(q0 + BQ, p.Nq) - 1;
+  const int kv_end = kv_limit(p, q_last);
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+  const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
+  const int full_vis_end = kv_limit(p, wave_q_first);
+
+  Stager<T, D, BKV> sk, sv;
+  if (ntiles > 0) {
+    sk.load(Kp, p.k_rs, 0, p.Nk, tid);
+    sv.load(Vp, p.v_rs, 0, p.Nk, tid);
+    sk.store(kimg(0), C::RSTRIDE, tid);
+    sv.store(vimg(0), C::RSTRIDE, tid);
+  }
+  __syncthreads();
+
+  const float c = p.scale * LOG2E;
+  f32x16 dq[C::DT];
+  zero_acc(dq);
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kb = t * BKV;
+    if (t + 1 < ntiles) {
+      sk.load(Kp, p.k_rs, kb + BKV, p.Nk, tid);
+      sv.load(Vp, p.v_rs, kb + BKV, p.Nk, tid);
+    }
+    const char* kt = kimg(t & 1);
+    const char* vt = vimg(t & 1);
+    const bool boundary = kb + BKV > full_vis_end;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+      for (int s = 0; s < C::KSTEPS; ++s) {
+        Frag<T> kf, vf;
+        frag_row<T>(kf, kt, C::RSTRIDE, 32 * u + li, s, lh);
+        frag_row<T>(vf, vt, C::RSTRIDE, 32 * u + li, s, lh);
+        mma32<T>(sc, kf, qf[s]);
+        mma32<T>(dp, vf, gf[s]);
+      }
+      const int qpos = qrow + p.q_off;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
+        if (boundary) {
+          const int key = kb + 32 * u + acc_row(r, lh);
+          if (!(key < p.Nk && visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))) pv = 0.0f;
+        }
+        sc[r] = pv * (dp[r] - dl);   // dS^T (without the softmax scale; folded into the final store)
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag<T> df;
+        frag_from_acc<T>(df, sc, s);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+          Frag<T> ktf;
+          frag_tr<T>(ktf, kt, C::RSTRIDE, 32 * u, s, 32 * dt, lane);
+          mma32<T>(dq[dt], ktf, df);
+        }
+      }
+    }
+    if (t + 1 < ntiles) {
+      sk.store(kimg((t + 1) & 1), C::RSTRIDE, tid);
+      sv.store(vimg((t + 1) & 1), C::RSTRIDE, tid);
+    }
+    __syncthreads();
+  }
+  T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
+  store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
+}
+
+// ================================================================================================= dK, dV
+// workgroup = 128 keys (wave = 32 keys, key on the lane); sweeps query tiles of 64 rows.
+template <typename T, int D>
+__global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs p) {
+  using C = AT<T, D>;
+  constexpr int TQ = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = TQ * C::RSTRIDE;
+  auto qimg = [&](int i) -> char* { return smem + i * IMG; };
+  auto gimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
+  float* stats = reinterpret_cast<float*>(smem + 4 * IMG);   // [2 buffers][2 (lse2, delta)][TQ]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y, k0 = blockIdx.x * 128;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const int krow = k0 + wave * 32 + li;
+  const bool k_ok = krow < p.Nk;
+
+  if constexpr (C::DPAD != D) {
+    for (int i = tid; i < 4 * IMG / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
+    __syncthreads();
+  }
+
+  Frag<T> kf[C::KSTEPS], vf[C::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s) {
+    if (k_ok) {
+      frag_load_contig<T>(kf[s], Kp + (int64_t)krow * p.k_rs + 16 * s + 8 * lh);
+      frag_load_contig<T>(vf[s], Vp + (int64_t)krow * p.v_rs + 16 * s + 8 * lh);
+    } else {
+      frag_zero<T>(kf[s]);
+      frag_zero<T>(vf[s]);
+    }
+  }
+
+  const int qs = (q_first(p, k0) / TQ) * TQ;                 // first query tile that can see key k0
+  const int ntiles = qs < p.Nq ? (p.Nq - qs + TQ - 1) / TQ : 0;
+  // queries >= this index see every key of this wave's 32 keys
+  const int full_vis_q = q_first(p, min(k0 + wave * 32 + 31, p.Nk - 1));
+  const int64_t stat0 = ((int64_t)b * p.H + hd) * p.Nq;
+
+  Stager<T, D, TQ> sq, sg;
+  float st_l = 0.0f, st_d = 0.0f;
+  auto load_stats = [&](int qb) {
+    if (tid < TQ) {
+      const int q = qb + tid;
+      st_l = q < p.Nq ? p.LSE[stat0 + q] * LOG2E : INFINITY;
+      st_d = q < p.Nq ? p.delta[stat0 + q] : 0.0f;
+    }
+  };
+  auto store_stats = [&](int buf) {
+    if (tid < TQ) {
+      stats[buf * 2 * TQ + tid] = st_l;
+      stats[buf * 2 * TQ + TQ + tid] = st_d;
+    }
+  };
+  if (ntiles > 0) {
+    sq.load(Qp, p.q_rs, qs, p.Nq, tid);
+    sg.load(Gp, p.o_rs, qs, p.Nq, tid);
+    load_stats(qs);
+    sq.store(qimg(0), C::RSTRIDE, tid);
+    sg.store(gimg(0), C::RSTRIDE, tid);
+    store_stats(0);
+  }
+  __syncthreads();
+
+  const float c = p.scale * LOG2E;
+  f32x16 dk[C::DT], dv[C::DT];
+  zero_acc(dk);
+  zero_acc(dv);
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int qb = qs + t * TQ;
+    if (t + 1 < ntiles) {
+      sq.load(Qp, p.q_rs, qb + TQ, p.Nq, tid);
+      sg.load(Gp, p.o_rs, qb + TQ, p.Nq, tid);
+      load_stats(qb + TQ);
+    }
+    const char* qt = qimg(t & 1);
+    const char* gt = gimg(t & 1);
+    const float* stl = stats + (t & 1) * 2 * TQ;
+    const float* std_ = stl + TQ;
+    const bool boundary = qb < full_vis_q;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+      for (int s = 0; s < C::KSTEPS; ++s) {
+        Frag<T> qf, gf;
+        frag_row<T>(qf, qt, C::RSTRIDE, 32 * u + li, s, lh);
+        frag_row<T>(gf, gt, C::RSTRIDE, 32 * u + li, s, lh);
+        mma32<T>(sc, qf, kf[s]);   // S[q][key]
+        mma32<T>(dp, gf, vf[s]);   // dP[q][key]
+      }
+      const int kpos = krow + p.k_off;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + 32 * u + 8 * g + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(std_ + 32 * u + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          float pv = __builtin_amdgcn_exp2f(sc[r] * c - l4[j]);
+          if (boundary) {
+            const int q = qb + 32 * u + acc_row(r, lh);
+            if (!(k_ok && visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))) pv = 0.0f;
+          }
+          if (!k_ok) pv = 0.0f;
+          sc[r] = pv;                       // P
+          dp[r] = pv * (dp[r] - d4[j]);     // dS (scale folded into the final store)
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag<T> pf, df;
+        frag_from_acc<T>(pf, sc, s);
+        frag_from_acc<T>(df, dp, s);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+          Frag<T> gtf, qtf;
+          frag_tr<T>(gtf, gt, C::RSTRIDE, 32 * u, s, 32 * dt, lane);
+          frag_tr<T>(qtf, qt, C::RSTRIDE, 32 * u, s, 32 * dt, lane);
+          mma32<T>(dv[dt], gtf, pf);   // dV^T[d][key] += dO^T P
+          mma32<T>(dk[dt], qtf, df);   // dK^T[d][key] += Q^T dS
+        }
+      }
+    }
+    if (t + 1 < ntiles) {
+      sq.store(qimg((t + 1) & 1), C::RSTRIDE, tid);
+      sg.store(gimg((t + 1) & 1), C::RSTRIDE, tid);
+      store_stats((t + 1) & 1);
+    }
+    __syncthreads();
+  }
+  T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
+  T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
+  store_rows_T<T, D>(dKp, p.k_rs, krow, k_ok, dk, p.scale, lh);
+  store_rows_T<T, D>(dVp, p.v_rs, krow, k_ok, dv, 1.0f, lh);
+}
+
+// ------------------------------------------------------------------------------------------------- host
+template <typename T, int D> size_t fwd_lds() { return 2 * BKV * (AT<T, D>::RSTRIDE + AT<T, D>::VSTRIDE); }
+template <typename T, int D> size_t dq_lds() { return 4 * BKV * AT<T, D>::RSTRIDE; }
+template <typename T, int D> size_t dkdv_lds() { return 4 * 64 * AT<T, D>::RSTRIDE + 4 * 64 * sizeof(float); }
+
+template <typename K> void allow_lds(K kernel, size_t bytes) {
+  if (bytes > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
+  dim3 grid((a.Nq + BQ - 1) / BQ, a.H, a.B);
+  const size_t lds = fwd_lds<T, D>();
+  allow_lds(attn_fwd_kernel<T, D>, lds);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(NT), lds, s, a);
+  return 0;
+}
+template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.B * a.H * a.Nq;
+  hipLaunchKernelGGL((attn_delta_kernel<T, D>), dim3((unsigned)fk_cdiv(total, 256)), dim3(256), 0, s, a);
+  dim3 gk((a.Nk + 127) / 128, a.H, a.B);
+  const size_t lds_kv = dkdv_lds<T, D>(), lds_q = dq_lds<T, D>();
+  allow_lds(attn_bwd_dkdv_kernel<T, D>, lds_kv);
+  allow_lds(attn_bwd_dq_kernel<T, D>, lds_q);
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D>), gk, dim3(NT), lds_kv, s, a);
+  dim3 gq((a.Nq + BQ - 1) / BQ, a.H, a.B);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), gq, dim3(NT), lds_q, s, a);
+  return 0;
+}
+
+int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D, int dtype, int mask_kind,
+                 int64_t mask_c, const int64_t* strides, int nstr) {
+  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "%s: bad dtype %d", name, dtype);
+  FK_CHECK_ARG(D == 16 || D == 32 || D == 64 || (D == 128 && dtype == FK_BF16),
+               "%s: head_dim %lld unsupported (16/32/64, 128 for bf16)", name, (long long)D);
+  FK_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B < 65536 && H < 65536 && Nq < (1LL << 30) && Nk < (1LL << 30),
+               "%s: bad shape B=%lld H=%lld Nq=%lld Nk=%lld", name, (long long)B, (long long)H, (long long)Nq, (long long)Nk);
+  FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL,
+               "%s: mask kind %d not supported", name, mask_kind);
+  FK_CHECK_ARG(mask_kind != FK_MASK_BLOCK_CAUSAL || mask_c > 0, "%s: block-causal mask needs block size > 0", name);
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  for (int i = 0; i < nstr; ++i)
+    FK_CHECK_ARG(strides[i] % vec == 0, "%s: strides must be multiples of %d elements (16 bytes)", name, vec);
+  return FK_OK;
+}
+
+#define FK_ATTN_DISPATCH(FN, args, stream)                                                   \
+  do {                                                                                        \
+    if (dtype == FK_BF16) {                                                                   \
+      switch (D) {                                                                            \
+        case 16: FN<bf16_t, 16>(args, stream); break;                                         \
+        case 32: FN<bf16_t, 32>(args, stream); break;                                         \
+        case 64: FN<bf16_t, 64>(args, stream); break;                                         \
+        default: FN<bf16_t, 128>(args, stream); break;                                        \
+      }                                                                                       \
+    } else {                                                                                  \
+      switch (D) {                                                                            \
+        case 16: FN<float, 16>(args, stream); break;                                          \
+        case 32: FN<float, 32>(args, stream); break;                                          \
+        default: FN<float, 64>(args, stream); break;                                          \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
+                int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
+                int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
+                float scale, int dtype, void* stream) {
+  const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
+  int rc = check_common("fk_attn_fwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
+  if (rc) return rc;
+  FK_CHECK_ARG(Q && K && V && O, "fk_attn_fwd: null pointer");
+  FK_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0, "fk_attn_fwd: pointers must be 16-byte aligned");
+  AttnArgs a{};
+  a.Q = Q; a.K = K; a.V = V; a.Out = O; a.LSE = LSE;
+  a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
+  a.B = (int)B; a.H = (int)H; a.Nq = (int)Nq; a.Nk = (int)Nk;
+  a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
+  FK_ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
+  FK_CHECK_LAUNCH("fk_attn_fwd");
+  return FK_OK;
+}
+
+int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
+                int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
+                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, float scale, int dtype,
+                void* stream) {
+  const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
+  int rc = check_common("fk_attn_bwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
+  if (rc) return rc;
+  FK_CHECK_ARG(Q && K && V && O && dO && LSE && dQ && dK && dV && delta_ws, "fk_attn_bwd: null pointer");
+  FK_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0,
+               "fk_attn_bwd: pointers must be 16-byte aligned");
+  AttnArgs a{};
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.LSE = const_cast<float*>(LSE); a.delta = delta_ws;
+  a.dQ = dQ; a.dK = dK; a.dV = dV;
+  a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
+  a.B = (int)B; a.H = (int)H; a.Nq = (int)Nq; a.Nk = (int)Nk;
+  a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
+  FK_ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
+  FK_CHECK_LAUNCH("fk_attn_bwd");
+  return FK_OK;
+}
+
+}  // extern "C"

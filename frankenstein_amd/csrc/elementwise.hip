@@ -1,0 +1,375 @@
+// elementwise.hip — HBM-bound pointwise / layout kernels of the hot path (SURVEY.md §2.3 K1, K4, K7 act, K8, K11).
+//   fk_rope       apply_rope                       models/brainformer.py:70-91
+//   fk_patchify   Rearrange('b (t p1) c -> b (t c) p1')  models/brainformer.py:282,338
+//   fk_swiglu_*   silu(w1 x) * w3 x                models/brainformer.py:124
+//   fk_gelu_*     nn.GELU() (exact erf)            models/gpt2_model.py:83,89
+//   fk_cast_pack / fk_cast / fk_add / fk_copy2d    weight-shadow and residual plumbing
+//   fk_embedding_*, fk_gpt_embed_fwd               nn.Embedding + prefix concat + wpe, models/gpt2_model.py:183-196
+// All bf16 traffic is 16-byte vectorised; math in fp32.
+#include "fk_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned grid_for(int64_t work, int64_t cap = 1 << 20) {
+  int64_t b = fk_cdiv(work, TPB);
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+template <typename T> struct V16;
+template <> struct V16<bf16_t> {
+  static constexpr int N = 8;
+  FK_DEV static void ld(const bf16_t* p, float (&v)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+  }
+  FK_DEV static void st(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+  }
+};
+template <> struct V16<float> {
+  static constexpr int N = 4;
+  FK_DEV static void ld(const float* p, float (&v)[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+  }
+  FK_DEV static void st(float* p, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = v[i];
+    *reinterpret_cast<f32x4*>(p) = a;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------- RoPE
+template <typename T>
+__global__ void rope_kernel(T* x, int64_t B, int64_t T_, int64_t ld, int rot_cols, int D, const float* table,
+                            int64_t table_bs, int64_t pos_off, float sgn) {
+  constexpr int N = V16<T>::N;
+  const int cpr = rot_cols / N;   // vector chunks per row
+  const int64_t total = B * T_ * cpr;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    const int64_t row = i / cpr, t = row % T_, b = row / T_;
+    const int col = ch * N, d = col % D;   // d even, chunk stays inside one head (D % N == 0)
+    T* px = x + row * ld + col;
+    const float* tb = table + b * table_bs + ((pos_off + t) * (D / 2) + d / 2) * 2;
+    float v[N], o[N];
+    V16<T>::ld(px, v);
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+      const float c = tb[2 * j], s = sgn * tb[2 * j + 1];
+      o[2 * j] = v[2 * j] * c - v[2 * j + 1] * s;
+      o[2 * j + 1] = v[2 * j] * s + v[2 * j + 1] * c;
+    }
+    V16<T>::st(px, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- patchify
+template <typename T>
+__global__ void patchify_kernel(const float* x, T* tok, int T_, int C, int P, int ldp) {
+  extern __shared__ float slab[];   // [P][C+1]
+  const int nT = T_ / P;
+  const int b = blockIdx.x / nT, t = blockIdx.x % nT;
+  const float* src = x + ((int64_t)b * T_ + (int64_t)t * P) * C;
+  for (int i = threadIdx.x; i < P * C; i += blockDim.x) slab[(i / C) * (C + 1) + (i % C)] = src[i];
+  __syncthreads();
+  T* dst = tok + ((int64_t)blockIdx.x * C) * ldp;
+  for (int i = threadIdx.x; i < C * ldp; i += blockDim.x) {
+    const int c = i / ldp, p = i % ldp;
+    dst[i] = from_f32<T>(p < P ? slab[p * (C + 1) + c] : 0.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- SwiGLU / GELU
+FK_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <typename T>
+__global__ void swiglu_fwd_kernel(const T* h13, T* g, int64_t rows, int H) {
+  constexpr int N = V16<T>::N;
+  const int cpr = H / N;
+  const int64_t total = rows * cpr;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i % cpr) * N;
+    float a[N], b[N], o[N];
+    V16<T>::ld(h13 + r * 2 * H + c, a);
+    V16<T>::ld(h13 + r * 2 * H + H + c, b);
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = a[j] * sigmoidf_(a[j]) * b[j];
+    V16<T>::st(g + r * H + c, o);
+  }
+}
+template <typename T>
+__global__ void swiglu_bwd_kernel(const T* h13, const T* dg, T* dh13, int64_t rows, int H) {
+  constexpr int N = V16<T>::N;
+  const int cpr = H / N;
+  const int64_t total = rows * cpr;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i % cpr) * N;
+    float a[N], b[N], d[N], oa[N], ob[N];
+    V16<T>::ld(h13 + r * 2 * H + c, a);
+    V16<T>::ld(h13 + r * 2 * H + H + c, b);
+    V16<T>::ld(dg + r * H + c, d);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float sg = sigmoidf_(a[j]);
+      oa[j] = d[j] * b[j] * sg * (1.0f + a[j] * (1.0f - sg));
+      ob[j] = d[j] * a[j] * sg;
+    }
+    V16<T>::st(dh13 + r * 2 * H + c, oa);
+    V16<T>::st(dh13 + r * 2 * H + H + c, ob);
+  }
+}
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* x, T* y, int64_t nvec) {
+  constexpr int N = V16<T>::N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[N], o[N];
+    V16<T>::ld(x + i * N, a);
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = 0.5f * a[j] * (1.0f + erff(a[j] * 0.70710678118654752f));
+    V16<T>::st(y + i * N, o);
+  }
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* x, const T* dy, T* dx, int64_t nvec) {
+  constexpr int N = V16<T>::N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[N], d[N], o[N];
+    V16<T>::ld(x + i * N, a);
+    V16<T>::ld(dy + i * N, d);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float cdf = 0.5f * (1.0f + erff(a[j] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * a[j] * a[j]);
+      o[j] = d[j] * (cdf + a[j] * pdf);
+    }
+    V16<T>::st(dx + i * N, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- casts / copies
+template <typename T>
+__global__ void cast_pack_kernel(const float* src, int64_t lds, T* dst, int64_t ldd, int rows, int cols, int transpose) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (transpose) {   // consecutive threads walk dst rows (= src columns): coalesced stores
+      const int r = (int)(i % rows), c = (int)(i / rows);
+      dst[(int64_t)c * ldd + r] = from_f32<T>(src[(int64_t)r * lds + c]);
+    } else {
+      const int r = (int)(i / cols), c = (int)(i % cols);
+      dst[(int64_t)r * ldd + c] = from_f32<T>(src[(int64_t)r * lds + c]);
+    }
+  }
+}
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* src, TD* dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = from_f32<TD>(to_f32<TS>(src[i]));
+}
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* y, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]));
+}
+template <typename T>
+__global__ void copy2d_kernel(const T* src, int64_t lds, T* dst, int64_t ldd, int64_t rows, int64_t cols) {
+  const int64_t total = rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    dst[(i / cols) * ldd + (i % cols)] = src[(i / cols) * lds + (i % cols)];
+}
+
+// ---------------------------------------------------------------------------------------------- embeddings
+// out[r, :] = (src_sel ? prefix row : table[idx]) + pos[t]   for the GPT prefix-concat embedding
+template <typename T>
+__global__ void gpt_embed_kernel(const int64_t* idx, const T* prefix, const float* wte, const float* wpe, T* out, int B,
+                                 int t_ctx, int t_words, int dim, int vocab) {
+  const int t_full = t_ctx + t_words;
+  const int64_t total = (int64_t)B * t_full * dim;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dim);
+    const int64_t row = i / dim;
+    const int t = (int)(row % t_full), b = (int)(row / t_full);
+    float v;
+    if (t < t_ctx) v = to_f32<T>(prefix[((int64_t)b * t_ctx + t) * dim + c]);
+    else {
+      int64_t id = idx[(int64_t)b * t_words + (t - t_ctx)];
+      id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+      v = wte[id * dim + c];
+    }
+    out[i] = from_f32<T>(v + wpe[(int64_t)t * dim + c]);
+  }
+}
+// dtable[idx[r]] += dout[row_map(r)]   (token rows only; fp32 atomics, rows = B*t_words is small)
+template <typename T>
+__global__ void embed_bwd_kernel(const int64_t* idx, const T* dout, int64_t ldo_rows_per_b, int t_ctx, int t_words,
+                                 float* dtable, int B, int dim, int vocab) {
+  const int64_t total = (int64_t)B * t_words * dim;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dim);
+    const int64_t r = i / dim;
+    const int j = (int)(r % t_words), b = (int)(r / t_words);
+    int64_t id = idx[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float g = to_f32<T>(dout[((int64_t)b * ldo_rows_per_b + t_ctx + j) * dim + c]);
+    atomicAdd(dtable + id * dim + c, g);
+  }
+}
+
+}  // namespace
+
+#define FK_DT_CHECK(name) FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, name ": bad dtype %d", dtype)
+
+extern "C" {
+
+int fk_rope(void* x, int64_t B, int64_t T, int64_t ld, int64_t nheads, int64_t D, const float* table, int64_t table_bs,
+            int64_t pos_off, int conj, int dtype, void* stream) {
+  FK_DT_CHECK("fk_rope");
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(x && table && B > 0 && T > 0 && nheads > 0, "fk_rope: bad arguments");
+  FK_CHECK_ARG(D % vec == 0 && D % 2 == 0 && ld % vec == 0 && nheads * D <= ld, "fk_rope: D=%lld ld=%lld must be multiples of %d", (long long)D, (long long)ld, vec);
+  FK_CHECK_ARG(((uintptr_t)x & 15) == 0, "fk_rope: x must be 16-byte aligned");
+  const int64_t work = B * T * (nheads * D / vec);
+  hipStream_t s = (hipStream_t)stream;
+  const float sgn = conj ? -1.0f : 1.0f;
+  if (dtype == FK_BF16)
+    hipLaunchKernelGGL(rope_kernel<bf16_t>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, (bf16_t*)x, B, T, ld, (int)(nheads * D), (int)D, table, table_bs, pos_off, sgn);
+  else
+    hipLaunchKernelGGL(rope_kernel<float>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, (float*)x, B, T, ld, (int)(nheads * D), (int)D, table, table_bs, pos_off, sgn);
+  FK_CHECK_LAUNCH("fk_rope");
+  return FK_OK;
+}
+
+int fk_patchify(const float* x, void* tok, int64_t B, int64_t T, int64_t C, int64_t P, int64_t ldp, int dtype, void* stream) {
+  FK_DT_CHECK("fk_patchify");
+  FK_CHECK_ARG(x && tok && B > 0 && T > 0 && C > 0 && P > 0 && T % P == 0 && ldp >= P, "fk_patchify: bad shape (T %% P must be 0, ldp >= P)");
+  const size_t sh = (size_t)P * (C + 1) * sizeof(float);
+  FK_CHECK_ARG(sh <= 65536, "fk_patchify: P*(C+1) slab of %zu bytes exceeds 64 KiB LDS", sh);
+  FK_CHECK_ARG(B * (T / P) < (1LL << 31), "fk_patchify: too many patches");
+  dim3 grid((unsigned)(B * (T / P)));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, dim3(TPB), sh, s, x, (bf16_t*)tok, (int)T, (int)C, (int)P, (int)ldp);
+  else hipLaunchKernelGGL(patchify_kernel<float>, grid, dim3(TPB), sh, s, x, (float*)tok, (int)T, (int)C, (int)P, (int)ldp);
+  FK_CHECK_LAUNCH("fk_patchify");
+  return FK_OK;
+}
+
+int fk_swiglu_fwd(const void* h13, void* g, int64_t rows, int64_t H, int dtype, void* stream) {
+  FK_DT_CHECK("fk_swiglu_fwd");
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(h13 && g && rows > 0 && H > 0 && H % vec == 0, "fk_swiglu_fwd: H must be a multiple of %d", vec);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t work = rows * (H / vec);
+  if (dtype == FK_BF16) hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_t>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, (const bf16_t*)h13, (bf16_t*)g, rows, (int)H);
+  else hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, (const float*)h13, (float*)g, rows, (int)H);
+  FK_CHECK_LAUNCH("fk_swiglu_fwd");
+  return FK_OK;
+}
+int fk_swiglu_bwd(const void* h13, const void* dg, void* dh13, int64_t rows, int64_t H, int dtype, void* stream) {
+  FK_DT_CHECK("fk_swiglu_bwd");
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(h13 && dg && dh13 && rows > 0 && H > 0 && H % vec == 0, "fk_swiglu_bwd: H must be a multiple of %d", vec);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t work = rows * (H / vec);
+  if (dtype == FK_BF16) hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_t>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, (const bf16_t*)h13, (const bf16_t*)dg, (bf16_t*)dh13, rows, (int)H);
+  else hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, (const float*)h13, (const float*)dg, (float*)dh13, rows, (int)H);
+  FK_CHECK_LAUNCH("fk_swiglu_bwd");
+  return FK_OK;
+}
+int fk_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+  FK_DT_CHECK("fk_gelu_fwd");
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(x && y && n > 0 && n % vec == 0, "fk_gelu_fwd: n must be a multiple of %d", vec);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, dim3(grid_for(n / vec, 16384)), dim3(TPB), 0, s, (const bf16_t*)x, (bf16_t*)y, n / vec);
+  else hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(grid_for(n / vec, 16384)), dim3(TPB), 0, s, (const float*)x, (float*)y, n / vec);
+  FK_CHECK_LAUNCH("fk_gelu_fwd");
+  return FK_OK;
+}
+int fk_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
+  FK_DT_CHECK("fk_gelu_bwd");
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(x && dy && dx && n > 0 && n % vec == 0, "fk_gelu_bwd: n must be a multiple of %d", vec);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(grid_for(n / vec, 16384)), dim3(TPB), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / vec);
+  else hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(grid_for(n / vec, 16384)), dim3(TPB), 0, s, (const float*)x, (const float*)dy, (float*)dx, n / vec);
+  FK_CHECK_LAUNCH("fk_gelu_bwd");
+  return FK_OK;
+}
+
+int fk_cast_pack(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
+                 int dtype, void* stream) {
+  FK_DT_CHECK("fk_cast_pack");
+  FK_CHECK_ARG(src && dst && rows > 0 && cols > 0 && rows < (1LL << 31) && cols < (1LL << 31), "fk_cast_pack: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(cast_pack_kernel<bf16_t>, dim3(grid_for(rows * cols, 8192)), dim3(TPB), 0, s, src, lds, (bf16_t*)dst, ldd, (int)rows, (int)cols, transpose);
+  else hipLaunchKernelGGL(cast_pack_kernel<float>, dim3(grid_for(rows * cols, 8192)), dim3(TPB), 0, s, src, lds, (float*)dst, ldd, (int)rows, (int)cols, transpose);
+  FK_CHECK_LAUNCH("fk_cast_pack");
+  return FK_OK;
+}
+int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+  FK_CHECK_ARG((src_dtype == FK_F32 || src_dtype == FK_BF16) && (dst_dtype == FK_F32 || dst_dtype == FK_BF16), "fk_cast: bad dtype");
+  FK_CHECK_ARG(src && dst && n > 0, "fk_cast: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(grid_for(n, 16384)), b(TPB);
+  if (src_dtype == FK_F32 && dst_dtype == FK_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == FK_BF16 && dst_dtype == FK_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == FK_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n);
+  else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+  FK_CHECK_LAUNCH("fk_cast");
+  return FK_OK;
+}
+int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
+  FK_DT_CHECK("fk_add");
+  FK_CHECK_ARG(a && b && y && n > 0, "fk_add: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(n, 16384)), dim3(TPB), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+  else hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n, 16384)), dim3(TPB), 0, s, (const float*)a, (const float*)b, (float*)y, n);
+  FK_CHECK_LAUNCH("fk_add");
+  return FK_OK;
+}
+int fk_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype, void* stream) {
+  FK_DT_CHECK("fk_copy2d");
+  FK_CHECK_ARG(src && dst && rows > 0 && cols > 0, "fk_copy2d: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(copy2d_kernel<bf16_t>, dim3(grid_for(rows * cols, 16384)), dim3(TPB), 0, s, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, rows, cols);
+  else hipLaunchKernelGGL(copy2d_kernel<float>, dim3(grid_for(rows * cols, 16384)), dim3(TPB), 0, s, (const float*)src, lds, (float*)dst, ldd, rows, cols);
+  FK_CHECK_LAUNCH("fk_copy2d");
+  return FK_OK;
+}
+
+int fk_gpt_embed_fwd(const int64_t* idx, const void* prefix, const float* wte, const float* wpe, void* out, int64_t B,
+                     int64_t t_ctx, int64_t t_words, int64_t dim, int64_t vocab, int dtype, void* stream) {
+  FK_DT_CHECK("fk_gpt_embed_fwd");
+  FK_CHECK_ARG(idx && wte && wpe && out && B > 0 && t_words > 0 && t_ctx >= 0 && dim > 0 && vocab > 0, "fk_gpt_embed_fwd: bad arguments");
+  FK_CHECK_ARG(t_ctx == 0 || prefix, "fk_gpt_embed_fwd: prefix is NULL but t_ctx > 0");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t work = B * (t_ctx + t_words) * dim;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(gpt_embed_kernel<bf16_t>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, idx, (const bf16_t*)prefix, wte, wpe, (bf16_t*)out, (int)B, (int)t_ctx, (int)t_words, (int)dim, (int)vocab);
+  else hipLaunchKernelGGL(gpt_embed_kernel<float>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, idx, (const float*)prefix, wte, wpe, (float*)out, (int)B, (int)t_ctx, (int)t_words, (int)dim, (int)vocab);
+  FK_CHECK_LAUNCH("fk_gpt_embed_fwd");
+  return FK_OK;
+}
+int fk_gpt_embed_bwd_wte(const int64_t* idx, const void* dout, float* dwte, int64_t B, int64_t t_ctx, int64_t t_words,
+                         int64_t dim, int64_t vocab, int dtype, void* stream) {
+  FK_DT_CHECK("fk_gpt_embed_bwd_wte");
+  FK_CHECK_ARG(idx && dout && dwte && B > 0 && t_words > 0 && dim > 0, "fk_gpt_embed_bwd_wte: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t work = B * t_words * dim;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, idx, (const bf16_t*)dout, t_ctx + t_words, (int)t_ctx, (int)t_words, dwte, (int)B, (int)dim, (int)vocab);
+  else hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, idx, (const float*)dout, t_ctx + t_words, (int)t_ctx, (int)t_words, dwte, (int)B, (int)dim, (int)vocab);
+  FK_CHECK_LAUNCH("fk_gpt_embed_bwd_wte");
+  return FK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,398 @@
+// gemm.hip — MFMA GEMMs for the projection / MLP / head layers (SURVEY.md §2.3 K3, K6, K7, K9 head).
+//
+//   fk_gemm_nt : C[M,N]  = A[M,K] * B[N,K]^T (+ bias[N]) (+ residual)      y = x W^T      (nn.Linear fwd;
+//                                                                         dx = dy (W^T)^T with a W^T shadow)
+//   fk_gemm_tn : C[N1,N2] (fp32) (+)= sum_m A[m,N1] * B[m,N2]             dW = dy^T x    (nn.Linear wgrad)
+//   fk_colsum  : out[c] (+)= sum_r X[r,c]                                  db = sum dy    (bias grads)
+//
+// Tiling (both GEMMs): 128x128 block tile, 4 waves as 2x2, each wave 2x2 MFMA 32x32 tiles (64 fp32
+// accumulators per lane); k-tiles of 128 bytes per row (64 bf16 / 32 fp32), double-buffered in LDS
+// (64 KiB -> 2 blocks per CU), global->register->LDS staging with the loads for tile t+1 in flight
+// during the MFMAs of tile t, one barrier per k-tile.
+// LDS images:
+//   NT: [row][128 B], 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7): ds_read_b128 fragment
+//       reads (same chunk, 16 different rows per lane group) are bank-conflict free.
+//   TN: [k-row][128 cols]; bf16 fragments are k-strided -> ds_read_b64_tr_b16 (4 rows x 16 cols per
+//       16-lane group); the 64-B granule g of row r is stored at granule g ^ (r&3) so the 4 rows of a
+//       block hit different banks.  fp32 fragments use ds_read_b32 (conflict free unswizzled).
+// blockIdx is remapped XCD-aware (xcd_remap) so tiles that share an A row panel share an L2.
+#include "fk_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int ROW_BYTES = 128;                 // NT image: bytes per k-tile row
+constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand tile
+
+template <typename T> struct KT;               // elements per k-tile
+template <> struct KT<bf16_t> { static constexpr int BK = 64, VEC = 8, STEPS = 4; };
+template <> struct KT<float> { static constexpr int BK = 32, VEC = 4, STEPS = 2; };
+
+FK_DEV int nt_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// fragment of k16-step s for tile row `row`, lane half h, from an NT image
+template <typename T> FK_DEV void nt_frag(Frag<T>& f, const char* tile, int row, int s, int h);
+template <> FK_DEV void nt_frag<bf16_t>(Frag<bf16_t>& f, const char* tile, int row, int s, int h) {
+  f.v = *reinterpret_cast<const bf16x8*>(tile + nt_off(row, 2 * s + h));
+}
+template <> FK_DEV void nt_frag<float>(Frag<float>& f, const char* tile, int row, int s, int h) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(tile + nt_off(row, 4 * s + 2 * h));
+  f32x4 b = *reinterpret_cast<const f32x4*>(tile + nt_off(row, 4 * s + 2 * h + 1));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f.v[e] = a[e]; f.v[4 + e] = b[e]; }
+}
+
+struct NtArgs {
+  const void* A; const void* B; void* C;
+  const void* bias; const void* res;
+  int64_t lda, ldb, ldc, ldr, res_rows;
+  int M, N, K;
+};
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = KT<T>::BK, VEC = KT<T>::VEC, STEPS = KT<T>::STEPS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ntn = (p.N + BN - 1) / BN;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(L / ntn) * BM, n0 = (int)(L % ntn) * BN;
+  const T* A = (const T*)p.A;
+  const T* B = (const T*)p.B;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + NTHREADS * i, row = id >> 3, ch = id & 7, k = k0 + ch * VEC;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ra[i] = (m0 + row < p.M && k < p.K) ? *reinterpret_cast<const u32x4*>(A + (int64_t)(m0 + row) * p.lda + k) : z;
+      rb[i] = (n0 + row < p.N && k < p.K) ? *reinterpret_cast<const u32x4*>(B + (int64_t)(n0 + row) * p.ldb + k) : z;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* as = smem + buf * 2 * TILE_BYTES;
+    char* bs = as + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + NTHREADS * i, row = id >> 3, ch = id & 7;
+      *reinterpret_cast<u32x4*>(as + nt_off(row, ch)) = ra[i];
+      *reinterpret_cast<u32x4*>(bs + nt_off(row, ch)) = rb[i];
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const char* as = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* bs = as + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      Frag<T> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) nt_frag<T>(fa[i], as, wm * 64 + i * 32 + li, s, lh);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+    }
+    if (kt + 1 < nk) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // epilogue: + bias[n] + residual[m % res_rows][n], cast, store (lane = column, registers = rows)
+  const T* bias = (const T*)p.bias;
+  const T* res = (const T*)p.res;
+  TO* C = (TO*)p.C;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + li;
+    if (n >= p.N) continue;
+    const float bv = bias ? to_f32<T>(bias[n]) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + acc_row(r, lh);
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (res) {
+          const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
+          v += to_f32<T>(res[rr * p.ldr + n]);
+        }
+        C[(int64_t)m * p.ldc + n] = from_f32<TO>(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ TN
+template <typename T> struct TNT;
+template <> struct TNT<bf16_t> { static constexpr int BKM = 64, ROWB = 256, CHUNKS = 16, STEPS = 4; };
+template <> struct TNT<float> { static constexpr int BKM = 32, ROWB = 512, CHUNKS = 32, STEPS = 2; };
+
+FK_DEV int tn_off_bf16(int row, int bytecol) {   // bytecol: byte offset inside the 256-B row
+  const int g = bytecol >> 6;
+  return row * 256 + (((g ^ (row & 3)) << 6) | (bytecol & 63));
+}
+
+// fragment of k16-step s for output columns cb..cb+31 of a TN image (k index = image row)
+template <typename T> FK_DEV void tn_frag(Frag<T>& f, const char* tile, int cb, int s, int lane);
+template <> FK_DEV void tn_frag<bf16_t>(Frag<bf16_t>& f, const char* tile, int cb, int s, int lane) {
+  const int g = lane >> 4, i = lane & 15, h = g >> 1;
+  const int col = cb + 16 * (g & 1) + 4 * (i & 3);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = 16 * s + 8 * h + 4 * t + (i >> 2);
+    bf16x4 v = lds_read_tr4(reinterpret_cast<const bf16_t*>(tile + tn_off_bf16(row, col * 2)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f.v[4 * t + e] = v[e];
+  }
+}
+template <> FK_DEV void tn_frag<float>(Frag<float>& f, const char* tile, int cb, int s, int lane) {
+  const int h = lane >> 5, c = cb + (lane & 31);
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    f.v[e] = *reinterpret_cast<const float*>(tile + (16 * s + 8 * h + e) * 512 + c * 4);
+}
+
+struct TnArgs {
+  const void* A; const void* B; float* C; float* ws;
+  int64_t lda, ldb, ldc;
+  int M, N1, N2, rows_per_split, nsplit, accumulate;
+};
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKM = TNT<T>::BKM, ROWB = TNT<T>::ROWB, CHUNKS = TNT<T>::CHUNKS, STEPS = TNT<T>::STEPS;
+  constexpr int VEC = KT<T>::VEC;
+  constexpr int LOG_CH = (CHUNKS == 16) ? 4 : 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int nt2 = (p.N2 + BN - 1) / BN;
+  const int a0 = (int)(blockIdx.x / nt2) * BM, b0 = (int)(blockIdx.x % nt2) * BN;
+  const int split = blockIdx.y;
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+  const T* A = (const T*)p.A;
+  const T* B = (const T*)p.B;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int mrow0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + NTHREADS * i, row = id >> LOG_CH, ch = id & (CHUNKS - 1);
+      const int m = mrow0 + row, ca = a0 + ch * VEC, cb = b0 + ch * VEC;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ra[i] = (m < mend && ca < p.N1) ? *reinterpret_cast<const u32x4*>(A + (int64_t)m * p.lda + ca) : z;
+      rb[i] = (m < mend && cb < p.N2) ? *reinterpret_cast<const u32x4*>(B + (int64_t)m * p.ldb + cb) : z;
+    }
+  };
+  auto lds_off = [&](int row, int ch) -> int {
+    if constexpr (sizeof(T) == 2) return tn_off_bf16(row, ch * 16);
+    else return row * ROWB + ch * 16;
+  };
+  auto lstore = [&](int buf) {
+    char* as = smem + buf * 2 * TILE_BYTES;
+    char* bs = as + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + NTHREADS * i, row = id >> LOG_CH, ch = id & (CHUNKS - 1);
+      *reinterpret_cast<u32x4*>(as + lds_off(row, ch)) = ra[i];
+      *reinterpret_cast<u32x4*>(bs + lds_off(row, ch)) = rb[i];
+    }
+  };
+
+  const int nk = (mend - mbeg + BKM - 1) / BKM;
+  if (nk > 0) {
+    gload(mbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(mbeg + (kt + 1) * BKM);
+    const char* as = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* bs = as + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      Frag<T> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) tn_frag<T>(fa[i], as, wm * 64 + i * 32, s, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tn_frag<T>(fb[j], bs, wn * 64 + j * 32, s, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+    }
+    if (kt + 1 < nk) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  float* out = (p.nsplit > 1) ? p.ws + (int64_t)split * p.N1 * p.N2 : p.C;
+  const int64_t ldo = (p.nsplit > 1) ? p.N2 : p.ldc;
+  const bool accum = (p.nsplit == 1) && p.accumulate;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = b0 + wn * 64 + j * 32 + li;
+    if (n >= p.N2) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = a0 + wm * 64 + i * 32 + acc_row(r, lh);
+        if (m >= p.N1) continue;
+        float* dst = out + (int64_t)m * ldo + n;
+        *dst = accum ? (*dst + acc[i][j][r]) : acc[i][j][r];
+      }
+  }
+}
+
+__global__ void reduce_slabs_kernel(const float* ws, float* C, int64_t ldc, int N1, int N2, int nsplit, int accumulate) {
+  const int64_t total = (int64_t)N1 * N2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int k = 0; k < nsplit; ++k) s += ws[k * total + i];
+    float* dst = C + (i / N2) * ldc + (i % N2);
+    *dst = accumulate ? (*dst + s) : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ colsum
+// out[c] (+)= sum_r X[r, c]; two stages through a [nblk, cols] fp32 workspace (deterministic).
+template <typename T>
+__global__ void colsum_partial_kernel(const T* X, int64_t ld, float* part, int rows, int cols, int rows_per_blk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  float s = 0.0f;
+  for (int r = r0; r < r1; ++r) s += to_f32<T>(X[(int64_t)r * ld + c]);
+  part[(int64_t)blockIdx.y * cols + c] = s;
+}
+__global__ void colsum_final_kernel(const float* part, float* out, int cols, int nblk, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int k = 0; k < nblk; ++k) s += part[(int64_t)k * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+int tn_splits(int64_t M, int64_t N1, int64_t N2, int bkm) {
+  const int64_t tiles = fk_cdiv(N1, BM) * fk_cdiv(N2, BN);
+  int64_t want = fk_cdiv(1024, tiles);                     // ~4 blocks per CU
+  const int64_t maxs = fk_cdiv(M, (int64_t)bkm * 4);        // >= 4 k-tiles per split
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+int colsum_blocks(int64_t rows) {
+  int64_t b = fk_cdiv(rows, 256);
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+               int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
+               int out_dtype, void* stream) {
+  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_gemm_nt: bad dtype %d", dtype);
+  FK_CHECK_ARG(out_dtype == dtype || out_dtype == FK_F32, "fk_gemm_nt: out_dtype must equal dtype or be f32");
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(M > 0 && N > 0 && K > 0, "fk_gemm_nt: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  FK_CHECK_ARG(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "fk_gemm_nt: dims must fit int32");
+  FK_CHECK_ARG(K % vec == 0 && lda % vec == 0 && ldb % vec == 0, "fk_gemm_nt: K/lda/ldb must be multiples of %d", vec);
+  FK_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "fk_gemm_nt: A/B must be 16-byte aligned");
+  FK_CHECK_ARG(A && B && C, "fk_gemm_nt: null pointer");
+  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K};
+  const int64_t nwg = fk_cdiv(M, BM) * fk_cdiv(N, BN);
+  dim3 grid((unsigned)nwg), block(NTHREADS);
+  const size_t sh = 4 * TILE_BYTES;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16 && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, sh, s, p);
+  else if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, sh, s, p);
+  else hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, sh, s, p);
+  FK_CHECK_LAUNCH("fk_gemm_nt");
+  return FK_OK;
+}
+
+size_t fk_gemm_tn_workspace_bytes(int64_t M, int64_t N1, int64_t N2, int dtype) {
+  const int ns = tn_splits(M, N1, N2, dtype == FK_BF16 ? 64 : 32);
+  return ns > 1 ? (size_t)ns * N1 * N2 * sizeof(float) : 0;
+}
+
+int fk_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N1,
+               int64_t N2, int accumulate, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_gemm_tn: bad dtype %d", dtype);
+  const int vec = dtype == FK_BF16 ? 8 : 4, bkm = dtype == FK_BF16 ? 64 : 32;
+  FK_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0, "fk_gemm_tn: empty problem");
+  FK_CHECK_ARG(M < (1LL << 31) && N1 < (1LL << 31) && N2 < (1LL << 31), "fk_gemm_tn: dims must fit int32");
+  FK_CHECK_ARG(N1 % vec == 0 && N2 % vec == 0 && lda % vec == 0 && ldb % vec == 0,
+               "fk_gemm_tn: N1/N2/lda/ldb must be multiples of %d (N1=%lld N2=%lld)", vec, (long long)N1, (long long)N2);
+  FK_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "fk_gemm_tn: A/B must be 16-byte aligned");
+  const int ns = tn_splits(M, N1, N2, bkm);
+  const size_t need = ns > 1 ? (size_t)ns * N1 * N2 * sizeof(float) : 0;
+  FK_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "fk_gemm_tn: workspace too small (%zu < %zu)", workspace_bytes, need);
+  int64_t rps = fk_cdiv(fk_cdiv(M, ns), bkm) * bkm;
+  TnArgs p{A, B, C, (float*)workspace, lda, ldb, ldc, (int)M, (int)N1, (int)N2, (int)rps, ns, accumulate};
+  dim3 grid((unsigned)(fk_cdiv(N1, BM) * fk_cdiv(N2, BN)), (unsigned)ns), block(NTHREADS);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 4 * TILE_BYTES, s, p);
+  else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 4 * TILE_BYTES, s, p);
+  FK_CHECK_LAUNCH("fk_gemm_tn");
+  if (ns > 1) {
+    const int64_t total = N1 * N2;
+    int nb = (int)fk_cdiv(total, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nb), dim3(256), 0, s, (const float*)workspace, C, ldc, (int)N1, (int)N2, ns, accumulate);
+    FK_CHECK_LAUNCH("fk_gemm_tn(reduce)");
+  }
+  return FK_OK;
+}
+
+size_t fk_colsum_workspace_bytes(int64_t rows, int64_t cols) { return (size_t)colsum_blocks(rows) * cols * sizeof(float); }
+
+int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols, int accumulate, int dtype,
+              void* workspace, size_t workspace_bytes, void* stream) {
+  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_colsum: bad dtype %d", dtype);
+  FK_CHECK_ARG(rows > 0 && cols > 0 && rows < (1LL << 31) && cols < (1LL << 31), "fk_colsum: bad shape");
+  const int nb = colsum_blocks(rows);
+  FK_CHECK_ARG(workspace && workspace_bytes >= (size_t)nb * cols * sizeof(float), "fk_colsum: workspace too small");
+  const int rpb = (int)fk_cdiv(rows, nb);
+  dim3 grid((unsigned)fk_cdiv(cols, 256), (unsigned)nb), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)X, ld, (float*)workspace, (int)rows, (int)cols, rpb);
+  else hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, block, 0, s, (const float*)X, ld, (float*)workspace, (int)rows, (int)cols, rpb);
+  FK_CHECK_LAUNCH("fk_colsum(partial)");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)fk_cdiv(cols, 256)), block, 0, s, (const float*)workspace, out, (int)cols, nb, accumulate);
+  FK_CHECK_LAUNCH("fk_colsum(final)");
+  return FK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// norm.hip — LayerNorm / RMSNorm forward + backward (HBM-bound).
+//
+// Replaces nn.LayerNorm(dim) (models/brainformer.py:237,239,252,254,287,500), F.layer_norm
+// (models/gpt2_model.py:27) and RMSNorm (models/brainformer.py:221-232) of the reference.
+// One wave per row (64 lanes x 16-byte vectors; the row stays in L1 between the three sweeps),
+// wave-shuffle reductions, fp32 statistics saved for the backward.  The backward fuses the
+// residual-branch gradient add (dx = dres + norm_bwd(dy)).  dgamma/dbeta are column reductions
+// through a [chunks, 2, dim] fp32 workspace (deterministic).
+#include "fk_common.h"
+
+namespace {
+
+template <typename T> struct VecIO;
+template <> struct VecIO<bf16_t> {
+  static constexpr int N = 8;
+  FK_DEV static void load(const bf16_t* p, float (&v)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+  }
+  FK_DEV static void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+  }
+};
+template <> struct VecIO<float> {
+  static constexpr int N = 4;
+  FK_DEV static void load(const float* p, float (&v)[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+  }
+  FK_DEV static void store(float* p, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = v[i];
+    *reinterpret_cast<f32x4*>(p) = a;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
+                                                        float* mean, float* rstd, int64_t rows, int dim, float eps, int kind) {
+  constexpr int N = VecIO<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += wstride) {
+    const T* xr = x + row * dim;
+    float s = 0.0f;
+    float v[N];
+    if (kind == FK_NORM_LAYER) {
+      for (int c = lane * N; c < dim; c += 64 * N) {
+        VecIO<T>::load(xr + c, v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) s += v[i];
+      }
+    }
+    const float mu = kind == FK_NORM_LAYER ? wave_sum(s) / dim : 0.0f;
+    float q = 0.0f;
+    for (int c = lane * N; c < dim; c += 64 * N) {
+      VecIO<T>::load(xr + c, v);
+#pragma unroll
+      for (int i = 0; i < N; ++i) q += (v[i] - mu) * (v[i] - mu);
+    }
+    const float rs = rsqrtf(wave_sum(q) / dim + eps);
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      rstd[row] = rs;
+    }
+    T* yr = y + row * dim;
+    for (int c = lane * N; c < dim; c += 64 * N) {
+      VecIO<T>::load(xr + c, v);
+      float o[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        float t = (v[i] - mu) * rs;
+        if (kind == FK_NORM_RMS && sizeof(T) == 2) t = (float)(bf16_t)t;   // reference: _norm(x.float()).type_as(x) * weight
+        o[i] = t * gamma[c + i] + (beta ? beta[c + i] : 0.0f);
+      }
+      VecIO<T>::store(yr + c, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                           const float* rstd, const T* dres, T* dx, int64_t rows, int dim, int kind) {
+  constexpr int N = VecIO<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += wstride) {
+    const T* xr = x + row * dim;
+    const T* gr = dy + row * dim;
+    const float mu = (kind == FK_NORM_LAYER) ? mean[row] : 0.0f, rs = rstd[row];
+    float s1 = 0.0f, s2 = 0.0f;
+    float xv[N], gv[N];
+    for (int c = lane * N; c < dim; c += 64 * N) {
+      VecIO<T>::load(xr + c, xv);
+      VecIO<T>::load(gr + c, gv);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const float dg = gv[i] * gamma[c + i];
+        s1 += dg;
+        s2 += dg * (xv[i] - mu) * rs;
+      }
+    }
+    const float c1 = (kind == FK_NORM_LAYER) ? wave_sum(s1) / dim : 0.0f;
+    const float c2 = wave_sum(s2) / dim;
+    for (int c = lane * N; c < dim; c += 64 * N) {
+      VecIO<T>::load(xr + c, xv);
+      VecIO<T>::load(gr + c, gv);
+      float o[N], rv[N];
+      if (dres) VecIO<T>::load(dres + row * dim + c, rv);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const float xh = (xv[i] - mu) * rs;
+        o[i] = rs * (gv[i] * gamma[c + i] - c1 - xh * c2) + (dres ? rv[i] : 0.0f);
+      }
+      VecIO<T>::store(dx + row * dim + c, o);
+    }
+  }
+}
+
+// partial[chunk][0][c] = sum_r dy*xhat, partial[chunk][1][c] = sum_r dy  over the chunk's rows
+template <typename T>
+__global__ void norm_bwd_param_partial(const T* dy, const T* x, const float* mean, const float* rstd, float* part,
+                                       int64_t rows, int dim, int rows_per_chunk, int kind) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dim) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float sg = 0.0f, sb = 0.0f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float g = to_f32<T>(dy[r * dim + c]);
+    const float mu = (kind == FK_NORM_LAYER) ? mean[r] : 0.0f;
+    sg += g * (to_f32<T>(x[r * dim + c]) - mu) * rstd[r];
+    sb += g;
+  }
+  part[((int64_t)blockIdx.y * 2) * dim + c] = sg;
+  part[((int64_t)blockIdx.y * 2 + 1) * dim + c] = sb;
+}
+__global__ void norm_bwd_param_final(const float* part, float* dgamma, float* dbeta, int dim, int nchunk, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dim) return;
+  float sg = 0.0f, sb = 0.0f;
+  for (int k = 0; k < nchunk; ++k) {
+    sg += part[((int64_t)k * 2) * dim + c];
+    sb += part[((int64_t)k * 2 + 1) * dim + c];
+  }
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sg : sg;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sb : sb;
+}
+
+int nchunks(int64_t rows) {
+  int64_t n = fk_cdiv(rows, 256);
+  if (n > 512) n = 512;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fk_norm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+                int64_t dim, float eps, int kind, int dtype, void* stream) {
+  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_norm_fwd: bad dtype %d", dtype);
+  FK_CHECK_ARG(kind == FK_NORM_LAYER || kind == FK_NORM_RMS, "fk_norm_fwd: bad kind %d", kind);
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(rows > 0 && dim > 0 && dim % vec == 0 && dim < (1 << 24), "fk_norm_fwd: dim %lld must be a multiple of %d", (long long)dim, vec);
+  FK_CHECK_ARG(x && y && gamma && rstd && (kind == FK_NORM_RMS || mean), "fk_norm_fwd: null pointer");
+  FK_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "fk_norm_fwd: x/y must be 16-byte aligned");
+  int64_t nb = fk_cdiv(rows, 4);
+  if (nb > 8192) nb = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16)
+    hipLaunchKernelGGL(norm_fwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, (int)dim, eps, kind);
+  else
+    hipLaunchKernelGGL(norm_fwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, (int)dim, eps, kind);
+  FK_CHECK_LAUNCH("fk_norm_fwd");
+  return FK_OK;
+}
+
+size_t fk_norm_bwd_workspace_bytes(int64_t rows, int64_t dim) { return (size_t)nchunks(rows) * 2 * dim * sizeof(float); }
+
+int fk_norm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t dim, int kind, int accumulate, int dtype,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_norm_bwd: bad dtype %d", dtype);
+  FK_CHECK_ARG(kind == FK_NORM_LAYER || kind == FK_NORM_RMS, "fk_norm_bwd: bad kind %d", kind);
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(rows > 0 && dim > 0 && dim % vec == 0, "fk_norm_bwd: dim %lld must be a multiple of %d", (long long)dim, vec);
+  FK_CHECK_ARG(dy && x && gamma && rstd && dx, "fk_norm_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t nb = fk_cdiv(rows, 4);
+  if (nb > 8192) nb = 8192;
+  if (dtype == FK_BF16)
+    hipLaunchKernelGGL(norm_bwd_dx_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, rows, (int)dim, kind);
+  else
+    hipLaunchKernelGGL(norm_bwd_dx_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, rows, (int)dim, kind);
+  FK_CHECK_LAUNCH("fk_norm_bwd(dx)");
+  if (dgamma || dbeta) {
+    const int nc = nchunks(rows);
+    FK_CHECK_ARG(workspace && workspace_bytes >= (size_t)nc * 2 * dim * sizeof(float), "fk_norm_bwd: workspace too small");
+    const int rpc = (int)fk_cdiv(rows, nc);
+    dim3 grid((unsigned)fk_cdiv(dim, 128), (unsigned)nc);
+    if (dtype == FK_BF16)
+      hipLaunchKernelGGL(norm_bwd_param_partial<bf16_t>, grid, dim3(128), 0, s, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, (float*)workspace, rows, (int)dim, rpc, kind);
+    else
+      hipLaunchKernelGGL(norm_bwd_param_partial<float>, grid, dim3(128), 0, s, (const float*)dy, (const float*)x, mean, rstd, (float*)workspace, rows, (int)dim, rpc, kind);
+    FK_CHECK_LAUNCH("fk_norm_bwd(partial)");
+    hipLaunchKernelGGL(norm_bwd_param_final, dim3((unsigned)fk_cdiv(dim, 128)), dim3(128), 0, s, (const float*)workspace, dgamma, dbeta, (int)dim, nc, accumulate);
+    FK_CHECK_LAUNCH("fk_norm_bwd(final)");
+  }
+  return FK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,457 @@
+"""Autograd glue between the nn.Module surface (models/) and the HIP kernels (kernels.py).
+
+Design (MI355X-first, not a translation of the reference's op graph):
+  * master parameters stay fp32; kernels consume compute-dtype *shadows* (bf16 or fp32) that are laid
+    out for the GEMMs: q/k/v (and w1/w3) concatenated into one [sum N, K] operand, plus a transposed
+    copy [K, sum N] so every activation GEMM — forward and dgrad — is the same K-contiguous NT kernel.
+  * the unit of autograd is the pre-norm residual branch ("sub-block"):  y = x + f(LN(x)).
+    One torch.autograd.Function per branch keeps exactly the tensors the hand-written backward
+    needs and fuses the residual-gradient add into the LayerNorm backward kernel.
+  * no torch math op is executed on the hot path: only allocation, views and kernel launches.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+from .kernels import Mask, NO_MASK
+
+Tensor = torch.Tensor
+
+_COMPUTE_DTYPE = torch.bfloat16
+_EPOCH = 0
+
+
+def set_compute_dtype(dtype) -> None:
+    """'bf16' (throughput mode: bf16 operands, fp32 accumulate) or 'fp32' (exact-fp32 MFMA parity mode)."""
+    global _COMPUTE_DTYPE
+    if isinstance(dtype, str):
+        dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[dtype]
+    assert dtype in (torch.bfloat16, torch.float32)
+    _COMPUTE_DTYPE = dtype
+
+
+def compute_dtype() -> torch.dtype:
+    return _COMPUTE_DTYPE
+
+
+def bump_weight_epoch() -> None:
+    """Called by the optimizer (which updates masters through raw pointers) to invalidate all shadows."""
+    global _EPOCH
+    _EPOCH += 1
+
+
+# --------------------------------------------------------------------------------------------- shadows
+class _Shadow:
+    __slots__ = ("stamp", "tensor")
+
+    def __init__(self):
+        self.stamp, self.tensor = None, None
+
+
+_SHADOWS: dict = {}
+
+
+def shadow(params: Sequence[Tensor], transpose: bool = False, pad_k: int = 0) -> Tensor:
+    """Compute-dtype copy of cat(params, dim=0) ([sum N, K]); transposed -> [K, sum N]; pad_k zero-pads K.
+    1-D params (biases) are concatenated as vectors.  Rebuilt only when a master changed."""
+    dt = _COMPUTE_DTYPE
+    key = (tuple(id(p) for p in params), transpose, pad_k)
+    stamp = (_EPOCH, dt, tuple(p._version for p in params), params[0].device, tuple(p.data_ptr() for p in params))
+    ent = _SHADOWS.get(key)
+    if ent is None:
+        ent = _SHADOWS[key] = _Shadow()
+    if ent.stamp == stamp:
+        return ent.tensor
+    p0 = params[0]
+    for p in params:
+        assert p.dtype == torch.float32, "master parameters must be float32 (compute dtype is set with set_compute_dtype)"
+    if p0.dim() == 1:
+        n = sum(p.numel() for p in params)
+        if dt == torch.float32 and len(params) == 1:
+            out = p0.detach()
+        else:
+            out = torch.empty(n, dtype=dt, device=p0.device)
+            off = 0
+            for p in params:
+                K.cast_pack(p.detach().view(1, -1), out[off:off + p.numel()].view(1, -1))
+                off += p.numel()
+    else:
+        Kd = p0.shape[1]
+        kp = max(Kd, pad_k)
+        n = sum(p.shape[0] for p in params)
+        if dt == torch.float32 and len(params) == 1 and not transpose and kp == Kd and p0.is_contiguous():
+            out = p0.detach()
+        else:
+            shape = (kp, n) if transpose else (n, kp)
+            out = (torch.zeros if kp != Kd else torch.empty)(shape, dtype=dt, device=p0.device)
+            off = 0
+            for p in params:
+                src = p.detach()
+                assert src.dim() == 2 and src.shape[1] == Kd and src.is_contiguous()
+                dst = out[:Kd, off:off + src.shape[0]] if transpose else out[off:off + src.shape[0], :Kd]
+                K.cast_pack(src, dst, transpose=transpose)
+                off += src.shape[0]
+    ent.stamp, ent.tensor = stamp, out
+    return out
+
+
+def _split_rows(t: Tensor, params: Sequence[Tensor]) -> List[Tensor]:
+    out, off = [], 0
+    for p in params:
+        n = p.shape[0]
+        out.append(t[off:off + n].view(p.shape))
+        off += n
+    return out
+
+
+def to_compute(x: Tensor) -> Tensor:
+    """fp32 / bf16 activation -> compute dtype (kernel cast, no autograd: inputs only)."""
+    if x.dtype == _COMPUTE_DTYPE:
+        return x.contiguous()
+    return K.cast(x.contiguous(), _COMPUTE_DTYPE)
+
+
+# --------------------------------------------------------------------------------------------- rope spec
+class Rope:
+    """fp32 (cos, sin) table [Tc, D/2, 2] (or per-sample [B, Tc, D/2, 2]); the LAST T rows are used
+    (models/brainformer.py:80,82)."""
+    __slots__ = ("table",)
+
+    def __init__(self, cache: Tensor):
+        t = torch.view_as_real(cache) if cache.is_complex() else cache
+        assert t.dtype == torch.float32 and t.shape[-1] == 2
+        self.table = t.contiguous()
+
+    def pos_off(self, T: int) -> int:
+        return self.table.shape[-3] - T
+
+
+# --------------------------------------------------------------------------------------------- functions
+class AttnBranch(torch.autograd.Function):
+    """y = [x +] proj(SDPA(rope(q), rope(k), v)) with q,k,v = Linear([LN](x));  one pre-norm attention branch.
+
+    Reference: Block.forward attention half (models/brainformer.py:243 with :147-173) and
+    gpt2 Block (models/gpt2_model.py:104 with :52-76)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, pw, pb, qkv_b, spec, *qkv_w):
+        H, D, mask, rope, residual, eps = spec
+        B, N, d = x.shape
+        M = B * N
+        x2 = x.view(M, d)
+        has_ln = ln_w is not None
+        if has_ln:
+            h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps)
+        else:
+            h, mean, rstd = x2, None, None
+        qkv = K.gemm_nt(h, shadow(qkv_w), bias=None if qkv_b is None else shadow([qkv_b]))
+        HD = H * D
+        qkv3 = qkv.view(B, N, 3 * HD)
+        if rope is not None:
+            K.rope_(qkv3, 2 * H, D, rope.table, rope.pos_off(N))
+        q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
+        o, lse = K.attn_fwd(q, k, v, mask)
+        y = K.gemm_nt(o.view(M, HD), shadow([pw]), bias=None if pb is None else shadow([pb]),
+                      residual=x2 if residual else None)
+        ctx.spec, ctx.has_ln, ctx.nw = spec, has_ln, len(qkv_w)
+        ctx.flags = (ln_b is not None, pb is not None, qkv_b is not None)
+        ctx.save_for_backward(x, ln_w, pw, *qkv_w, h if has_ln else None, mean, rstd, qkv, o, lse)
+        return y.view(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, D, mask, rope, residual, eps = ctx.spec
+        sv = ctx.saved_tensors
+        x, ln_w, pw = sv[0], sv[1], sv[2]
+        qkv_w = sv[3:3 + ctx.nw]
+        h, mean, rstd, qkv, o, lse = sv[3 + ctx.nw:]
+        has_lnb, has_pb, has_qb = ctx.flags
+        B, N, d = x.shape
+        M, HD = B * N, H * D
+        x2 = x.view(M, d)
+        if h is None:
+            h = x2
+        dy2 = dy.contiguous().view(M, -1)
+        do = K.gemm_nt(dy2, shadow([pw], transpose=True))
+        dpw = K.gemm_tn(dy2, o.view(M, HD))
+        dpb = K.colsum(dy2) if has_pb else None
+        dqkv = torch.empty_like(qkv)
+        qkv3, dqkv3 = qkv.view(B, N, 3 * HD), dqkv.view(B, N, 3 * HD)
+        q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
+        dq, dk, dv = (dqkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
+        K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask)
+        if rope is not None:
+            K.rope_(dqkv3, 2 * H, D, rope.table, rope.pos_off(N), conj=True)
+        dh = K.gemm_nt(dqkv, shadow(qkv_w, transpose=True))
+        dw = K.gemm_tn(dqkv, h)
+        dqb = K.colsum(dqkv) if has_qb else None
+        if ctx.has_ln:
+            dx, dg, db = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, want_beta=has_lnb)
+        else:
+            dx, dg, db = (K.add(dh, dy2) if residual else dh), None, None
+        return (dx.view(B, N, d), dg, db, dpw, dpb, dqb, None, *_split_rows(dw, qkv_w))
+
+
+class CrossAttnBranch(torch.autograd.Function):
+    """y = x + proj(SDPA(q = Wq LN(x), k = Wk ctx, v = Wv ctx))  (models/brainformer.py:262 with :198-219)."""
+
+    @staticmethod
+    def forward(ctx, x, context, ln_w, ln_b, qw, kw, vw, pw, spec):
+        H, D, mask, eps = spec
+        B, T, d = x.shape
+        Nc = context.shape[1]
+        HD = H * D
+        x2, c2 = x.view(B * T, d), context.view(B * Nc, d)
+        h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), ln_b.detach(), eps)
+        q = K.gemm_nt(h, shadow([qw]))
+        kv = K.gemm_nt(c2, shadow([kw, vw]))
+        kv3 = kv.view(B, Nc, 2 * HD)
+        o, lse = K.attn_fwd(q.view(B, T, H, D), kv3[..., :HD].unflatten(-1, (H, D)), kv3[..., HD:].unflatten(-1, (H, D)), mask)
+        y = K.gemm_nt(o.view(B * T, HD), shadow([pw]), residual=x2)
+        ctx.spec = spec
+        ctx.save_for_backward(x, context, ln_w, qw, kw, vw, pw, h, mean, rstd, q, kv, o, lse)
+        return y.view(B, T, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, D, mask, eps = ctx.spec
+        x, context, ln_w, qw, kw, vw, pw, h, mean, rstd, q, kv, o, lse = ctx.saved_tensors
+        B, T, d = x.shape
+        Nc, HD = context.shape[1], H * D
+        x2, c2 = x.view(B * T, d), context.view(B * Nc, d)
+        dy2 = dy.contiguous().view(B * T, d)
+        do = K.gemm_nt(dy2, shadow([pw], transpose=True))
+        dpw = K.gemm_tn(dy2, o.view(B * T, HD))
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        kv3, dkv3 = kv.view(B, Nc, 2 * HD), dkv.view(B, Nc, 2 * HD)
+        K.attn_bwd(q.view(B, T, H, D), kv3[..., :HD].unflatten(-1, (H, D)), kv3[..., HD:].unflatten(-1, (H, D)), o,
+                   do.view(B, T, H, D), lse, dq.view(B, T, H, D), dkv3[..., :HD].unflatten(-1, (H, D)),
+                   dkv3[..., HD:].unflatten(-1, (H, D)), mask)
+        dh = K.gemm_nt(dq, shadow([qw], transpose=True))
+        dqw = K.gemm_tn(dq, h)
+        dctx = K.gemm_nt(dkv, shadow([kw, vw], transpose=True))
+        dkvw = K.gemm_tn(dkv, c2)
+        dx, dg, db = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2)
+        dkw, dvw = _split_rows(dkvw, [kw, vw])
+        return dx.view(B, T, d), dctx.view(B, Nc, d), dg, db, dqw, dkw, dvw, dpw, None
+
+
+class MlpBranch(torch.autograd.Function):
+    """y = [x +] W2 act(W1 [LN](x)):  SwiGLU (w1,w3 -> silu*gate -> w2, models/brainformer.py:115-124,244) when
+    ``gate_w`` is given, GELU-erf MLP with biases (models/gpt2_model.py:87-92,105) otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, up_w, up_b, gate_w, down_w, down_b, spec):
+        residual, eps = spec
+        shp = x.shape
+        d = shp[-1]
+        x2 = x.reshape(-1, d)
+        has_ln = ln_w is not None
+        if has_ln:
+            h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps)
+        else:
+            h, mean, rstd = x2, None, None
+        ups = [up_w] if gate_w is None else [up_w, gate_w]
+        a = K.gemm_nt(h, shadow(ups), bias=None if up_b is None else shadow([up_b]))
+        g = K.gelu_fwd(a) if gate_w is None else K.swiglu_fwd(a)
+        y = K.gemm_nt(g, shadow([down_w]), bias=None if down_b is None else shadow([down_b]),
+                      residual=x2 if residual else None)
+        ctx.spec, ctx.has_ln = spec, has_ln
+        ctx.flags = (ln_b is not None, up_b is not None, gate_w is not None, down_b is not None)
+        ctx.save_for_backward(x, ln_w, up_w, gate_w, down_w, h if has_ln else None, mean, rstd, a, g)
+        return y.view(*shp[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        residual, eps = ctx.spec
+        x, ln_w, up_w, gate_w, down_w, h, mean, rstd, a, g = ctx.saved_tensors
+        has_lnb, has_ub, gated, has_db = ctx.flags
+        shp = x.shape
+        d = shp[-1]
+        x2 = x.reshape(-1, d)
+        if h is None:
+            h = x2
+        dy2 = dy.contiguous().view(x2.shape[0], -1)
+        ups = [up_w, gate_w] if gated else [up_w]
+        dg_ = K.gemm_nt(dy2, shadow([down_w], transpose=True))
+        ddown = K.gemm_tn(dy2, g)
+        ddb = K.colsum(dy2) if has_db else None
+        da = K.swiglu_bwd(a, dg_) if gated else K.gelu_bwd(a, dg_)
+        dh = K.gemm_nt(da, shadow(ups, transpose=True))
+        dups = _split_rows(K.gemm_tn(da, h), ups)
+        dub = K.colsum(da) if has_ub else None
+        if ctx.has_ln:
+            dx, dgam, dbet = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, want_beta=has_lnb)
+        else:
+            dx, dgam, dbet = (K.add(dh, dy2) if residual else dh), None, None
+        return (dx.view(shp), dgam, dbet, dups[0], dub, dups[1] if gated else None, ddown, ddb, None)
+
+
+class NormLinear(torch.autograd.Function):
+    """y = Linear([LN](x)) (+ bias);  heads (perceiver.ln_f -> to_motion / to_words, lm_head) and plain Linears."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w, b, eps, out_fp32):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        has_ln = ln_w is not None
+        if has_ln:
+            h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps)
+        else:
+            h, mean, rstd = x2, None, None
+        y = K.gemm_nt(h, shadow([w]), bias=None if b is None else shadow([b]),
+                      out_dtype=torch.float32 if out_fp32 else None)
+        ctx.has_ln, ctx.flags = has_ln, (ln_b is not None, b is not None)
+        ctx.save_for_backward(x, ln_w, w, h if has_ln else None, mean, rstd)
+        return y.view(*shp[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_w, w, h, mean, rstd = ctx.saved_tensors
+        has_lnb, has_b = ctx.flags
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if h is None:
+            h = x2
+        dy2 = dy.contiguous().view(x2.shape[0], -1)
+        if dy2.dtype != x2.dtype:
+            dy2 = K.cast(dy2, x2.dtype)
+        dh = K.gemm_nt(dy2, shadow([w], transpose=True))
+        dw = K.gemm_tn(dy2, h) if _tn_ok(dy2, h) else _gemm_tn_padded(dy2, h)
+        db = K.colsum(dy2) if has_b else None
+        if ctx.has_ln:
+            dx, dg, dbe = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, want_beta=has_lnb)
+        else:
+            dx, dg, dbe = dh, None, None
+        return dx.view(shp), dg, dbe, dw, db, None, None
+
+
+def _tn_ok(a: Tensor, b: Tensor) -> bool:
+    vec = 8 if a.dtype == torch.bfloat16 else 4
+    return a.shape[1] % vec == 0 and b.shape[1] % vec == 0
+
+
+def _gemm_tn_padded(a: Tensor, b: Tensor) -> Tensor:
+    """dW for an output width that is not a multiple of the 16-byte vector (e.g. vocab 50257): pad the dy
+    operand's columns with zeros into a scratch copy (head-sized; off the encoder's critical path)."""
+    vec = 8 if a.dtype == torch.bfloat16 else 4
+    n1 = (a.shape[1] + vec - 1) // vec * vec
+    ap = torch.zeros((a.shape[0], n1), dtype=a.dtype, device=a.device)
+    K.copy2d(a, ap[:, :a.shape[1]])
+    return K.gemm_tn(ap, b)[:a.shape[1]]
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, kind):
+        y, mean, rstd = K.norm_fwd(x.contiguous(), w.detach(), None if b is None else b.detach(), eps, kind)
+        ctx.kind, ctx.has_b = kind, b is not None
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dx, dg, db = K.norm_bwd(dy.contiguous(), x.contiguous(), w.detach(), mean, rstd, kind=ctx.kind, want_beta=ctx.has_b)
+        return dx, dg, db, None, None
+
+
+class PatchEmbed(torch.autograd.Function):
+    """tokens = Linear(patch -> dim)(to_patches(x)) + space_embedding[c]  (models/brainformer.py:338-343).
+    x is data (no gradient); K (= patch size) is zero-padded to a 16-byte multiple for the GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, emb_w, emb_b, space, P):
+        B, T, Cn = x.shape
+        d = emb_w.shape[0]
+        dt = _COMPUTE_DTYPE
+        kp = (P + 31) // 32 * 32
+        xin = x if x.dtype == torch.float32 else K.cast(x.contiguous(), torch.float32)
+        tok = K.patchify(xin.contiguous(), P, kp, dt)
+        sp = shadow([space.view(Cn, d)])
+        h = K.gemm_nt(tok, shadow([emb_w], pad_k=kp), bias=shadow([emb_b]), residual=sp, res_rows=Cn)
+        ctx.dims = (B, T // P, Cn, d, P)
+        ctx.save_for_backward(tok)
+        return h.view(B, (T // P) * Cn, d)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (tok,) = ctx.saved_tensors
+        B, nT, Cn, d, P = ctx.dims
+        dh2 = dh.contiguous().view(-1, d)
+        dw = K.gemm_tn(dh2, tok)[:, :P].contiguous()
+        db = K.colsum(dh2)
+        dspace = K.colsum(dh2.view(B * nT, Cn * d)).view(1, Cn, d)
+        return None, dw, db, dspace, None
+
+
+class ExpandQueries(torch.autograd.Function):
+    """learnable_queries [1,M,d] (fp32 master) -> [B,M,d] compute dtype (models/brainformer.py:545)."""
+
+    @staticmethod
+    def forward(ctx, qparam, B):
+        _, M, d = qparam.shape
+        row = shadow([qparam.view(1, M * d)])
+        out = torch.empty((B, M * d), dtype=row.dtype, device=row.device)
+        K.copy2d(row.expand(B, M * d), out)
+        ctx.shape = (M, d)
+        return out.view(B, M, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        M, d = ctx.shape
+        return K.colsum(dy.contiguous().view(-1, M * d)).view(1, M, d), None
+
+
+class L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, squared):
+        tgt = target if target.dtype == pred.dtype else K.cast(target.contiguous(), pred.dtype)
+        p = pred.contiguous()
+        ctx.squared = squared
+        ctx.save_for_backward(p, tgt.contiguous())
+        return K.l1_loss_fwd(p, tgt.contiguous(), squared)[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, tgt = ctx.saved_tensors
+        g = gout.reshape(1).float().contiguous()
+        return K.l1_loss_bwd(p, tgt, g, ctx.squared), None, None
+
+
+class CrossEntropy(torch.autograd.Function):
+    """mean NLL over rows whose target != ignore_index; logits [rows, V] (any row stride)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        loss2, lse = K.ce_loss_fwd(logits, targets.contiguous(), ignore_index)
+        ctx.ignore = ignore_index
+        ctx.save_for_backward(logits, targets, lse, loss2)
+        return loss2[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, targets, lse, loss2 = ctx.saved_tensors
+        g = gout.reshape(1).float().contiguous()
+        d = torch.empty(logits.shape, dtype=logits.dtype, device=logits.device)
+        return K.ce_loss_bwd(logits, targets.contiguous(), lse, loss2, g, d, ctx.ignore), None, None
+
+
+def cross_entropy(logits: Tensor, targets: Tensor, ignore_index: int = -100) -> Tensor:
+    V = logits.shape[-1]
+    lg = logits.reshape(-1, V) if logits.is_contiguous() else logits
+    if lg.dim() != 2:
+        lg = logits.contiguous().view(-1, V)
+    return CrossEntropy.apply(lg, targets.reshape(-1), ignore_index)
+
+
+def l1_loss(pred: Tensor, target: Tensor) -> Tensor:
+    return L1Loss.apply(pred, target, False)
+
+
+def mse_loss(pred: Tensor, target: Tensor) -> Tensor:
+    return L1Loss.apply(pred, target, True)

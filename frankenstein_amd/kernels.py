@@ -1,0 +1,337 @@
+"""Tensor-level wrappers over the C ABI (shape checks, output/scratch allocation through
+PyTorch's caching allocator, current HIP stream).  No math happens here and there is no
+fallback: every function ends in a libfranken_hip.so call.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_NONE, NORM_LAYER, NORM_RMS, call, lib
+
+Tensor = torch.Tensor
+
+
+def fk_dtype(t) -> int:
+    dt = t if isinstance(t, torch.dtype) else t.dtype
+    if dt == torch.bfloat16:
+        return FK_BF16
+    if dt == torch.float32:
+        return FK_F32
+    raise TypeError(f"frankenstein_amd kernels support float32 / bfloat16, got {dt}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes: int, device) -> Tuple[Optional[Tensor], int]:
+    if nbytes == 0:
+        return None, 0
+    w = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return w, nbytes
+
+
+def _as2d(t: Tensor) -> Tensor:
+    assert t.stride(-1) == 1, "innermost dim must be contiguous"
+    if t.dim() == 2:
+        return t
+    return t.reshape(-1, t.shape[-1])
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def gemm_nt(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+            res_rows: int = 0, out_dtype: Optional[torch.dtype] = None, out: Optional[Tensor] = None) -> Tensor:
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ bias) (+ residual[m % res_rows])."""
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
+    assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    odt = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == odt
+    if bias is not None:
+        assert bias.dtype == a.dtype and bias.numel() == N and bias.is_contiguous()
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == a.dtype and residual.dim() == 2 and residual.stride(1) == 1 and residual.shape[1] == N
+        ldr = residual.stride(0)
+    call("fk_gemm_nt", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+         _ptr(bias), _ptr(residual), ldr, res_rows, fk_dtype(a), fk_dtype(odt), _stream())
+    return out
+
+
+def gemm_tn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """out[N1,N2] (fp32) (+)= a[M,N1]^T @ b[M,N2]."""
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.dtype == b.dtype
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    if out is None:
+        assert not accumulate
+        out = torch.empty((N1, N2), dtype=torch.float32, device=a.device)
+    assert out.shape == (N1, N2) and out.dtype == torch.float32 and out.stride(1) == 1
+    ws, nb = _ws(lib().fk_gemm_tn_workspace_bytes(M, N1, N2, fk_dtype(a)), a.device)
+    call("fk_gemm_tn", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N1, N2,
+         int(accumulate), fk_dtype(a), _ptr(ws), nb, _stream())
+    return out
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    assert out.numel() == cols and out.dtype == torch.float32 and out.is_contiguous()
+    ws, nb = _ws(lib().fk_colsum_workspace_bytes(rows, cols), x.device)
+    call("fk_colsum", x.data_ptr(), x.stride(0), out.data_ptr(), rows, cols, int(accumulate), fk_dtype(x), _ptr(ws), nb,
+         _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------- attention
+class Mask:
+    """Analytic attention mask: kind in {none, causal, block_causal(C)} with position offsets
+    (the reference slices its [N,N] buffer as mask[..., -t_q:, -t_k:], models/brainformer.py:160-162)."""
+    __slots__ = ("kind", "c", "q_off", "k_off")
+
+    def __init__(self, kind: int = MASK_NONE, c: int = 0, q_off: int = 0, k_off: int = 0):
+        self.kind, self.c, self.q_off, self.k_off = kind, c, q_off, k_off
+
+    def sliced(self, n_full_q: int, n_full_k: int, t_q: int, t_k: int) -> "Mask":
+        return Mask(self.kind, self.c, self.q_off + n_full_q - t_q, self.k_off + n_full_k - t_k)
+
+
+NO_MASK = Mask()
+
+
+def _bnhd(t: Tensor):
+    assert t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3], "need [B,N,H,D] with heads packed in a row"
+    return t.stride(0), t.stride(1)
+
+
+def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optional[float] = None,
+             out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """q [B,Nq,H,D], k/v [B,Nk,H,D] (strided views ok) -> (o [B,Nq,H,D], lse [B,H,Nq] fp32)."""
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    assert k.shape == (B, Nk, H, D) and v.shape == (B, Nk, H, D) and q.dtype == k.dtype == v.dtype
+    if out is None:
+        out = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    (qb, qr), (kb, kr), (vb, vr), (ob, orr) = _bnhd(q), _bnhd(k), _bnhd(v), _bnhd(out)
+    sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    call("fk_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
+         qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, sc, fk_dtype(q), _stream())
+    return out, lse
+
+
+def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
+             mask: Mask = NO_MASK, scale: Optional[float] = None) -> None:
+    """Writes dq/dk/dv (same strides as q/k/v); do must have o's strides."""
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    (qb, qr), (kb, kr), (vb, vr), (ob, orr) = _bnhd(q), _bnhd(k), _bnhd(v), _bnhd(o)
+    assert _bnhd(dq) == (qb, qr) and _bnhd(dk) == (kb, kr) and _bnhd(dv) == (vb, vr) and _bnhd(do) == (ob, orr)
+    assert do.dtype == q.dtype and dq.dtype == q.dtype
+    delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    call("fk_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
+         mask.kind, mask.c, mask.q_off, mask.k_off, sc, fk_dtype(q), _stream())
+
+
+# ------------------------------------------------------------------------------------------- norms
+def norm_fwd(x: Tensor, gamma: Tensor, beta: Optional[Tensor], eps: float, kind: int = NORM_LAYER):
+    x2 = _as2d(x)
+    assert x2.is_contiguous() and gamma.dtype == torch.float32
+    rows, dim = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("fk_norm_fwd", x2.data_ptr(), gamma.data_ptr(), _ptr(beta), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+         rows, dim, eps, kind, fk_dtype(x), _stream())
+    return y.view(x.shape), mean, rstd
+
+
+def norm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
+             kind: int = NORM_LAYER, want_beta: bool = True):
+    """returns (dx, dgamma, dbeta) with dx = dres + norm_bwd(dy)."""
+    x2, dy2 = _as2d(x), _as2d(dy)
+    assert x2.is_contiguous() and dy2.is_contiguous() and dy2.dtype == x2.dtype
+    rows, dim = x2.shape
+    dx = torch.empty_like(x2)
+    dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(dim, dtype=torch.float32, device=x.device) if want_beta else None
+    dres2 = None
+    if dres is not None:
+        dres2 = _as2d(dres)
+        assert dres2.is_contiguous() and dres2.dtype == x2.dtype
+    ws, nb = _ws(lib().fk_norm_bwd_workspace_bytes(rows, dim), x.device)
+    call("fk_norm_bwd", dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres2),
+         dx.data_ptr(), dgamma.data_ptr(), _ptr(dbeta), rows, dim, kind, 0, fk_dtype(x), _ptr(ws), nb, _stream())
+    return dx.view(x.shape), dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------- pointwise
+def rope_(x: Tensor, nheads: int, D: int, table: Tensor, pos_off: int = 0, conj: bool = False) -> Tensor:
+    """In place on the first nheads*D columns of each row of x [B,T,ld]; table fp32 [Tc, D/2, 2] or [B, Tc, D/2, 2]."""
+    assert x.dim() == 3 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[-1] == 2 and table.shape[-2] == D // 2
+    B, T, _ = x.shape
+    tbs = 0
+    if table.dim() == 4:
+        assert table.shape[0] == B
+        tbs = table.stride(0)
+    assert pos_off >= 0 and pos_off + T <= table.shape[-3], "rope cache shorter than the sequence"
+    call("fk_rope", x.data_ptr(), B, T, x.stride(1), nheads, D, table.data_ptr(), tbs, pos_off, int(conj), fk_dtype(x), _stream())
+    return x
+
+
+def patchify(x: Tensor, P: int, ldp: int, dtype: torch.dtype) -> Tensor:
+    assert x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()
+    B, T, Cc = x.shape
+    tok = torch.empty((B * (T // P) * Cc, ldp), dtype=dtype, device=x.device)
+    call("fk_patchify", x.data_ptr(), tok.data_ptr(), B, T, Cc, P, ldp, fk_dtype(dtype), _stream())
+    return tok
+
+
+def swiglu_fwd(h13: Tensor) -> Tensor:
+    assert h13.dim() == 2 and h13.is_contiguous()
+    rows, H2 = h13.shape
+    g = torch.empty((rows, H2 // 2), dtype=h13.dtype, device=h13.device)
+    call("fk_swiglu_fwd", h13.data_ptr(), g.data_ptr(), rows, H2 // 2, fk_dtype(h13), _stream())
+    return g
+
+
+def swiglu_bwd(h13: Tensor, dg: Tensor) -> Tensor:
+    assert h13.is_contiguous() and dg.is_contiguous()
+    rows, H2 = h13.shape
+    d = torch.empty_like(h13)
+    call("fk_swiglu_bwd", h13.data_ptr(), dg.data_ptr(), d.data_ptr(), rows, H2 // 2, fk_dtype(h13), _stream())
+    return d
+
+
+def gelu_fwd(x: Tensor) -> Tensor:
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    call("fk_gelu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), fk_dtype(x), _stream())
+    return y
+
+
+def gelu_bwd(x: Tensor, dy: Tensor) -> Tensor:
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    call("fk_gelu_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), fk_dtype(x), _stream())
+    return dx
+
+
+def cast_pack(src: Tensor, dst: Tensor, transpose: bool = False) -> Tensor:
+    """dst[r, c] = src[r, c] (or dst[c, r]) ; src fp32 [rows, cols], dst pre-allocated (may be wider: zero padded by caller)."""
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1 and dst.dim() == 2 and dst.stride(1) == 1
+    rows, cols = src.shape
+    call("fk_cast_pack", src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), rows, cols, int(transpose),
+         fk_dtype(dst), _stream())
+    return dst
+
+
+def cast(src: Tensor, dtype: torch.dtype) -> Tensor:
+    assert src.is_contiguous()
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    call("fk_cast", src.data_ptr(), fk_dtype(src), dst.data_ptr(), fk_dtype(dtype), src.numel(), _stream())
+    return dst
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype
+    y = torch.empty_like(a)
+    call("fk_add", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), fk_dtype(a), _stream())
+    return y
+
+
+def copy2d(src: Tensor, dst: Tensor) -> Tensor:
+    assert src.dim() == 2 and dst.shape == src.shape and src.stride(1) == 1 and dst.stride(1) == 1 and src.dtype == dst.dtype
+    call("fk_copy2d", src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), src.shape[0], src.shape[1],
+         fk_dtype(src), _stream())
+    return dst
+
+
+# ------------------------------------------------------------------------------------------- losses
+def l1_loss_fwd(pred: Tensor, target: Tensor, squared: bool = False) -> Tensor:
+    assert pred.is_contiguous() and target.is_contiguous() and pred.shape == target.shape and pred.dtype == target.dtype
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    ws, nb = _ws(lib().fk_loss_workspace_bytes(pred.numel()), pred.device)
+    call("fk_l1_loss_fwd", pred.data_ptr(), target.data_ptr(), loss.data_ptr(), pred.numel(), int(squared),
+         fk_dtype(pred), _ptr(ws), nb, _stream())
+    return loss
+
+
+def l1_loss_bwd(pred: Tensor, target: Tensor, gout: Tensor, squared: bool = False) -> Tensor:
+    assert gout.dtype == torch.float32 and gout.numel() == 1
+    d = torch.empty_like(pred)
+    call("fk_l1_loss_bwd", pred.data_ptr(), target.data_ptr(), gout.data_ptr(), d.data_ptr(), pred.numel(), int(squared),
+         fk_dtype(pred), _stream())
+    return d
+
+
+def ce_loss_fwd(logits: Tensor, targets: Tensor, ignore_index: int = -100):
+    """logits [rows, V] (row stride ok), targets int64 [rows] -> (loss2 fp32[2] = {mean nll, count}, row_lse)."""
+    assert logits.dim() == 2 and logits.stride(1) == 1 and targets.dtype == torch.int64 and targets.is_contiguous()
+    rows, V = logits.shape
+    assert targets.numel() == rows
+    loss2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    ws, nb = _ws(lib().fk_ce_workspace_bytes(rows), logits.device)
+    call("fk_ce_loss_fwd", logits.data_ptr(), logits.stride(0), targets.data_ptr(), loss2.data_ptr(), lse.data_ptr(),
+         rows, V, ignore_index, fk_dtype(logits), _ptr(ws), nb, _stream())
+    return loss2, lse
+
+
+def ce_loss_bwd(logits: Tensor, targets: Tensor, lse: Tensor, loss2: Tensor, gout: Tensor, dlogits: Tensor,
+                ignore_index: int = -100) -> Tensor:
+    rows, V = logits.shape
+    assert dlogits.shape == logits.shape and dlogits.stride(1) == 1 and dlogits.dtype == logits.dtype
+    call("fk_ce_loss_bwd", logits.data_ptr(), logits.stride(0), targets.data_ptr(), lse.data_ptr(), loss2.data_ptr(),
+         gout.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), rows, V, ignore_index, fk_dtype(logits), _stream())
+    return dlogits
+
+
+# ------------------------------------------------------------------------------------------- GPT embedding
+def gpt_embed_fwd(idx: Tensor, prefix: Optional[Tensor], wte: Tensor, wpe: Tensor, dtype: torch.dtype) -> Tensor:
+    B, t_words = idx.shape
+    t_ctx = 0 if prefix is None else prefix.shape[1]
+    dim = wte.shape[1]
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and wte.dtype == torch.float32 and wpe.dtype == torch.float32
+    assert wte.is_contiguous() and wpe.is_contiguous() and wpe.shape[0] >= t_ctx + t_words
+    if prefix is not None:
+        assert prefix.is_contiguous() and prefix.dtype == dtype and prefix.shape == (B, t_ctx, dim)
+    out = torch.empty((B, t_ctx + t_words, dim), dtype=dtype, device=idx.device)
+    call("fk_gpt_embed_fwd", idx.data_ptr(), _ptr(prefix), wte.data_ptr(), wpe.data_ptr(), out.data_ptr(), B, t_ctx,
+         t_words, dim, wte.shape[0], fk_dtype(dtype), _stream())
+    return out
+
+
+def gpt_embed_bwd_wte(idx: Tensor, dout: Tensor, dwte: Tensor, t_ctx: int) -> None:
+    B, t_words = idx.shape
+    assert dout.is_contiguous() and dwte.dtype == torch.float32 and dwte.is_contiguous()
+    call("fk_gpt_embed_bwd_wte", idx.data_ptr(), dout.data_ptr(), dwte.data_ptr(), B, t_ctx, t_words, dwte.shape[1],
+         dwte.shape[0], fk_dtype(dout), _stream())
+
+
+# ------------------------------------------------------------------------------------------- optimizer
+def adamw_step_(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float = 0.9,
+                beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 1e-2, clip: float = 0.0,
+                grad_scale: float = 1.0, zero_grad: bool = False) -> None:
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    call("fk_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+         weight_decay, step, clip, grad_scale, int(zero_grad), _stream())

@@ -1,0 +1,150 @@
+/* franken_hip.h — C ABI of libfranken_hip.so: the MI355X (gfx950) hot path of the
+ * brainformer / GPT-2 decoder training step.
+ *
+ * The reference (ALVI-Labs/frankenstein) is pure Python on PyTorch: it has no FFI / plugin
+ * interface, so each entry point below replaces a *PyTorch op call site* of the reference
+ * (file:line given per function, relative to the reference root).  Conventions:
+ *   - plain pointers + sizes only (device pointers unless stated), no torch types;
+ *   - the library never allocates or frees device memory: outputs and scratch are caller
+ *     allocated, scratch size comes from the matching *_workspace_bytes() query;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and returns immediately; no host synchronisation inside (graph-capturable);
+ *   - return 0 on success, a negative FK_E* code otherwise; fk_last_error() returns a
+ *     thread-local message.  Nothing throws across the boundary.
+ *   - dtype: FK_F32 (exact-fp32 MFMA parity mode) or FK_BF16 (bf16 operands, fp32 accumulate).
+ */
+#ifndef FRANKEN_HIP_H
+#define FRANKEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FK_VERSION 100
+
+#define FK_OK 0
+#define FK_EINVAL (-1)       /* bad shape / dtype / alignment / null pointer */
+#define FK_ELAUNCH (-2)      /* hipGetLastError() after launch */
+#define FK_EUNSUPPORTED (-3)
+
+enum { FK_F32 = 0, FK_BF16 = 1 };
+enum { FK_MASK_NONE = 0, FK_MASK_CAUSAL = 1, FK_MASK_BLOCK_CAUSAL = 2 };
+enum { FK_NORM_LAYER = 0, FK_NORM_RMS = 1 };
+enum { FK_ACT_SWIGLU = 0, FK_ACT_GELU = 1 };
+
+int fk_version(void);
+const char* fk_last_error(void);
+
+/* ---- GEMM (nn.Linear: models/brainformer.py:119-124,141-145,149,171,285,342,501; models/gpt2_model.py:35,37,56,75,82-90,133,205)
+ * fk_gemm_nt: C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (+ residual[m % res_rows, n]); row-major, ld* in elements.
+ *   A,B,bias,residual have `dtype`; C has `out_dtype` (= dtype, or FK_F32).  res_rows = 0 means one residual
+ *   row per output row; res_rows = R broadcasts an [R, N] table over rows (the space embedding of
+ *   models/brainformer.py:343).  K, lda, ldb multiples of 16 bytes.                                          */
+int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+               int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
+               int out_dtype, void* stream);
+/* fk_gemm_tn: C[N1,N2] (fp32) (+)= sum_m A[m,N1] * B[m,N2]  — the weight gradient dW = dY^T X of a Linear
+ *   (autograd of the call sites above).  Split over m with deterministic slab reduction.                     */
+size_t fk_gemm_tn_workspace_bytes(int64_t M, int64_t N1, int64_t N2, int dtype);
+int fk_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N1,
+               int64_t N2, int accumulate, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* fk_colsum: out[c] (+)= sum_r X[r,c]  (bias / space-embedding gradients).                                   */
+size_t fk_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols, int accumulate, int dtype,
+              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused attention (F.scaled_dot_product_attention: models/brainformer.py:168,215; models/gpt2_model.py:64)
+ * Q,K,V,O are [B, N, H, D] views: element (b,n,h,d) at base + b*bs + n*rs + h*D + d.  LSE [B,H,Nq] fp32.
+ * mask: NONE | CAUSAL (k + k_off <= q + q_off) | BLOCK_CAUSAL ((k + k_off)/mask_c <= (q + q_off)/mask_c), the
+ * analytic form of build_advanced_causal_mask (models/brainformer.py:93-111) incl. the [-t_q:, -t_k:] slice (:160-162).
+ * Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
+ * Q/K/V's strides; delta_ws is [B,H,Nq] fp32 scratch.                                                        */
+int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
+                int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
+                int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
+                float scale, int dtype, void* stream);
+int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
+                int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
+                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, float scale, int dtype,
+                void* stream);
+
+/* ---- normalisation (nn.LayerNorm: models/brainformer.py:237,239,252,254,287,500; F.layer_norm models/gpt2_model.py:27;
+ *      RMSNorm models/brainformer.py:221-232).  x,y [rows, dim] contiguous; gamma/beta fp32 (beta may be NULL);
+ *      mean/rstd fp32 [rows] saved for backward (mean unused for RMS).                                        */
+int fk_norm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                int64_t rows, int64_t dim, float eps, int kind, int dtype, void* stream);
+/* dx = (dres ? dres : 0) + norm_bwd(dy); dgamma/dbeta (fp32, +=  when accumulate) via workspace partials.     */
+size_t fk_norm_bwd_workspace_bytes(int64_t rows, int64_t dim);
+int fk_norm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t dim, int kind,
+                int accumulate, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- RoPE (apply_rope, models/brainformer.py:70-91): in place on the first n_rot_heads*D columns of each row of
+ *      x [B, T, ld]; interleaved pairs rotated by table[(pos_off + t)] ([.., D/2, 2] fp32 = (cos, sin), i.e.
+ *      torch.view_as_real of the reference's complex cache); table_bs = 0 for a shared 2-D cache, else the per-sample
+ *      stride of a 3-D cache.  conj != 0 rotates by -angle (the backward).                                     */
+int fk_rope(void* x, int64_t B, int64_t T, int64_t ld, int64_t nheads, int64_t D, const float* table, int64_t table_bs,
+            int64_t pos_off, int conj, int dtype, void* stream);
+
+/* ---- patch tokeniser (Rearrange 'b (t p1) c -> b (t c) p1', models/brainformer.py:282,338): x fp32 [B,T,C] ->
+ *      tok [B*(T/P)*C, ldp] in `dtype`, columns >= P zero-filled (ldp >= P, multiple of 16 bytes).              */
+int fk_patchify(const float* x, void* tok, int64_t B, int64_t T, int64_t C, int64_t P, int64_t ldp, int dtype,
+                void* stream);
+
+/* ---- gated / pointwise MLP activations.  SwiGLU (models/brainformer.py:124): h13 [rows, 2*H] = [w1 x | w3 x],
+ *      g = silu(h1) * h3.  GELU exact erf (models/gpt2_model.py:83,89).                                        */
+int fk_swiglu_fwd(const void* h13, void* g, int64_t rows, int64_t H, int dtype, void* stream);
+int fk_swiglu_bwd(const void* h13, const void* dg, void* dh13, int64_t rows, int64_t H, int dtype, void* stream);
+int fk_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int fk_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+
+/* ---- dtype / layout plumbing for weight shadows: dst[r*ldd + c] = src[r*lds + c] (or transposed: dst[c*ldd + r]).*/
+int fk_cast_pack(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
+                 int dtype, void* stream);
+int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* y = a + b (same dtype) */
+int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+
+/* 2-D strided copy (same dtype): dst[r*ldd + c] = src[r*lds + c]. */
+int fk_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype, void* stream);
+
+/* ---- GPT input embedding (models/gpt2_model.py:183-196): out[b, t, :] = (t < t_ctx ? prefix[b, t, :]
+ *      : wte[idx[b, t - t_ctx], :]) + wpe[t, :];  wte/wpe are the fp32 master tables, prefix/out have `dtype`.
+ *      Backward of the wte gather: dwte[idx[b, j], :] += dout[b, t_ctx + j, :] (fp32 atomics; dwte is the same
+ *      buffer the tied lm_head gradient accumulates into, models/gpt2_model.py:138).                          */
+int fk_gpt_embed_fwd(const int64_t* idx, const void* prefix, const float* wte, const float* wpe, void* out, int64_t B,
+                     int64_t t_ctx, int64_t t_words, int64_t dim, int64_t vocab, int dtype, void* stream);
+int fk_gpt_embed_bwd_wte(const int64_t* idx, const void* dout, float* dwte, int64_t B, int64_t t_ctx, int64_t t_words,
+                         int64_t dim, int64_t vocab, int dtype, void* stream);
+
+/* ---- losses.  L1 (F.l1_loss, models/brainformer.py:557) / MSE (F.mse_loss, :473), mean reduction: loss fp32[1];
+ *      bwd: dpred = grad_out[0] * d(loss)/d(pred) with grad_out a DEVICE scalar (no host sync).
+ *      CE (F.cross_entropy ignore_index mean, models/gpt2_model.py:210; train_brainformer.ipynb cell 3):
+ *      logits [rows, V] (ld), targets int64 [rows]; loss2 = {mean nll over valid rows, #valid}; row_lse [rows].  */
+size_t fk_loss_workspace_bytes(int64_t n);
+int fk_l1_loss_fwd(const void* pred, const void* target, float* loss, int64_t n, int squared, int dtype,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int fk_l1_loss_bwd(const void* pred, const void* target, const float* grad_out, void* dpred, int64_t n, int squared,
+                   int dtype, void* stream);
+size_t fk_ce_workspace_bytes(int64_t rows);
+int fk_ce_loss_fwd(const void* logits, int64_t ld, const int64_t* targets, float* loss2, float* row_lse, int64_t rows,
+                   int64_t V, int64_t ignore_index, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+int fk_ce_loss_bwd(const void* logits, int64_t ld, const int64_t* targets, const float* row_lse, const float* loss2,
+                   const float* grad_out, void* dlogits, int64_t ldd, int64_t rows, int64_t V, int64_t ignore_index,
+                   int dtype, void* stream);
+
+/* ---- optimizer: torch.optim.AdamW step fused with clip_grad_value_ (utils/train_utils.py:117-119,142-143) over a
+ *      flat fp32 arena: g' = clamp(g * grad_scale, -clip, clip) (clip <= 0: no clamp); p *= 1 - lr*wd;
+ *      m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).
+ *      step is 1-based.  zero_grad != 0 also clears g (optimizer.zero_grad of the next step, :134).              */
+int fk_adamw_step(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int64_t step, double clip, double grad_scale, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRANKEN_HIP_H */

@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports exactly the
+symbols include/franken_hip.h declares (no compute calls: there is no GPU here)."""
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_symbols():
+    txt = (ROOT / "include" / "franken_hip.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fk_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from frankenstein_amd import build
+    return build.build(verbose=False)
+
+
+def test_header_and_binding_agree(built):
+    from frankenstein_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    assert sorted(_lib.SIGNATURES) == syms, set(_lib.SIGNATURES) ^ set(syms)
+
+
+def test_library_loads_and_exports_every_symbol(built):
+    import ctypes
+    from frankenstein_amd import _lib
+    h = ctypes.CDLL(str(built))
+    for s in declared_symbols():
+        assert hasattr(h, s), f"{s} declared in include/franken_hip.h but not exported"
+    lib = _lib.lib()
+    assert lib.fk_version() == 100
+    assert lib.fk_last_error() is not None
+
+
+def test_argument_validation_needs_no_gpu(built):
+    """Bad arguments are rejected on the host before any launch (error convention of SURVEY §8b)."""
+    from frankenstein_amd import _lib
+    lib = _lib.lib()
+    rc = lib.fk_gemm_nt(None, 0, None, 0, None, 0, 0, 0, 0, None, None, 0, 0, 7, 0, None)
+    assert rc == -1 and b"dtype" in lib.fk_last_error()
+    rc = lib.fk_gemm_nt(16, 12, 16, 12, 16, 8, 8, 8, 12, None, None, 0, 0, _lib.FK_BF16, _lib.FK_BF16, None)
+    assert rc == -1 and b"multiples" in lib.fk_last_error()
+    rc = lib.fk_attn_fwd(16, 16, 16, 16, None, 1, 1, 8, 8, 24, 0, 24, 0, 24, 0, 24, 0, 24, 0, 0, 0, 0, 1.0, 0, None)
+    assert rc == -1 and b"head_dim" in lib.fk_last_error()
+    rc = lib.fk_patchify(16, 16, 1, 10, 4, 3, 8, 0, None)
+    assert rc == -1
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from frankenstein_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.FrankenHipError, match="no CPU / PyTorch fallback"):
+        _lib.lib()

@@ -1,0 +1,355 @@
+"""Kernel-level parity on the MI355X: every C-ABI entry point against the CPU oracle primitives
+(oracle/ref_models.py, oracle/ref_train.py) on seeded inputs.  fp32 mode is held to ~1e-5,
+bf16 mode to bf16 rounding of a reference computed from the same bf16-rounded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_models as R
+from oracle import ref_train as RT
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from frankenstein_amd import kernels
+    return kernels
+
+
+def dev(t, dtype=None):
+    t = t.to("cuda")
+    return t.to(dtype) if dtype is not None else t
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """round-trip through the compute dtype so the reference sees the same operand values"""
+    return t.to(dtype).float().clone()
+
+
+def close(got, want, dtype, atol32=2e-5, rtol32=2e-5, atol16=None, rtol16=2e-2):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    if dtype == torch.float32:
+        torch.testing.assert_close(got, want, atol=atol32, rtol=rtol32)
+    else:
+        a = atol16 if atol16 is not None else 2e-2 * max(1.0, float(want.abs().max()))
+        torch.testing.assert_close(got, want, atol=a, rtol=rtol16)
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nt_exact_integers(K, dtype):
+    # asymmetric small-integer operands: products/sums exact in both dtypes -> catches any fragment / C-layout swap
+    M, N, Kd = 200, 136, 72
+    a = torch.randint(-3, 4, (M, Kd), generator=torch.Generator().manual_seed(1)).float()
+    w = torch.randint(-3, 4, (N, Kd), generator=torch.Generator().manual_seed(2)).float()
+    w[:, 0] += torch.arange(N) % 5
+    got = K.gemm_nt(dev(a, dtype), dev(w, dtype), out_dtype=torch.float32)
+    assert torch.equal(got.cpu(), a @ w.t())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(300, 200, 64), (128, 128, 384), (1000, 1003, 128), (64, 32, 32), (777, 384, 1536)])
+def test_gemm_nt(K, dtype, shape):
+    M, N, Kd = shape
+    a, w = rnd(M, Kd, seed=1), rnd(N, Kd, seed=2, scale=1 / math.sqrt(Kd))
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = q(a, dtype) @ q(w, dtype).t()
+    close(K.gemm_nt(dev(a, dtype), dev(w, dtype)), ref, dtype)
+    close(K.gemm_nt(dev(a, dtype), dev(w, dtype), bias=dev(bias, dtype), residual=dev(res, dtype)),
+          ref + q(bias, dtype) + q(res, dtype), dtype)
+    tab = rnd(7, N, seed=5)
+    want = ref + q(tab, dtype)[torch.arange(M) % 7]
+    close(K.gemm_nt(dev(a, dtype), dev(w, dtype), residual=dev(tab, dtype), res_rows=7, out_dtype=torch.float32), want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nt_strided_views(K, dtype):
+    big = dev(rnd(100, 3 * 64, seed=1), dtype)
+    a = big[:, 64:128]
+    w = dev(rnd(48, 64, seed=2), dtype)
+    out = torch.zeros(100, 96, device="cuda", dtype=dtype)
+    K.gemm_nt(a, w, out=out[:, 48:])
+    close(out[:, 48:], a.float().cpu() @ w.float().cpu().t(), dtype)
+    assert float(out[:, :48].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_tn_exact_integers(K, dtype):
+    M, N1, N2 = 333, 136, 72
+    a = torch.randint(-2, 3, (M, N1), generator=torch.Generator().manual_seed(1)).float()
+    b = torch.randint(-2, 3, (M, N2), generator=torch.Generator().manual_seed(2)).float()
+    b[:, 1] += torch.arange(M) % 3
+    got = K.gemm_tn(dev(a, dtype), dev(b, dtype))
+    assert torch.equal(got.cpu(), a.t() @ b)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(1000, 136, 264), (4113, 384, 32), (70, 64, 64), (20000, 128, 512)])
+def test_gemm_tn(K, dtype, shape):
+    M, N1, N2 = shape
+    a, b = rnd(M, N1, seed=1), rnd(M, N2, seed=2)
+    ref = q(a, dtype).t() @ q(b, dtype)
+    got = K.gemm_tn(dev(a, dtype), dev(b, dtype))
+    close(got, ref, torch.float32, atol32=2e-3 if dtype == torch.float32 else 5e-2 * math.sqrt(M / 1000), rtol32=1e-4 if dtype == torch.float32 else 2e-2)
+    acc = torch.ones(N1, N2, device="cuda")
+    K.gemm_tn(dev(a, dtype), dev(b, dtype), out=acc, accumulate=True)
+    close(acc, ref + 1, torch.float32, atol32=2e-3 if dtype == torch.float32 else 5e-2 * math.sqrt(M / 1000), rtol32=1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_colsum(K, dtype):
+    x = rnd(5000, 200, seed=3)
+    close(K.colsum(dev(x, dtype)), q(x, dtype).sum(0), torch.float32, atol32=1e-3, rtol32=1e-4)
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def ref_attn(qh, kh, vh, mask):
+    """q,k,v [B,N,H,D] fp32 cpu -> o [B,Nq,H,D]"""
+    o = R.sdpa(qh.transpose(1, 2), kh.transpose(1, 2), vh.transpose(1, 2), mask)
+    return o.transpose(1, 2)
+
+
+def mask_tensor(kind, c, Nq, Nk, q_off=0, k_off=0):
+    if kind == 0:
+        return None
+    qi = torch.arange(Nq)[:, None] + q_off
+    ki = torch.arange(Nk)[None, :] + k_off
+    return (ki <= qi) if kind == 1 else (ki // c) <= (qi // c)
+
+
+ATTN_CASES = [
+    # B, H, Nq, Nk, D, kind, c
+    (2, 3, 128, 128, 64, 0, 0),
+    (1, 2, 200, 200, 64, 2, 8),
+    (2, 2, 57, 57, 32, 1, 0),
+    (1, 4, 32, 300, 64, 0, 0),
+    (2, 4, 128, 128, 16, 2, 16),
+    (1, 2, 8, 8, 16, 0, 0),
+    (1, 2, 512, 512, 64, 2, 256),
+    (1, 1, 320, 320, 32, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(K, dtype, case):
+    B, H, Nq, Nk, D, kind, c = case
+    qkv_q = rnd(B, Nq, H * D, seed=1)
+    qkv_k = rnd(B, Nk, 2 * H * D, seed=2)
+    do = rnd(B, Nq, H, D, seed=3)
+    # device: q in its own buffer, k/v packed side by side (exercises strides)
+    qd = dev(qkv_q, dtype).view(B, Nq, H, D)
+    kvd = dev(qkv_k, dtype)
+    kd, vd = kvd[..., : H * D].unflatten(-1, (H, D)), kvd[..., H * D:].unflatten(-1, (H, D))
+    m = K.Mask(kind, c)
+    o, lse = K.attn_fwd(qd, kd, vd, m)
+    qr = q(qkv_q, dtype).view(B, Nq, H, D).requires_grad_(True)
+    kr = q(qkv_k[..., : H * D], dtype).reshape(B, Nk, H, D).requires_grad_(True)
+    vr = q(qkv_k[..., H * D:], dtype).reshape(B, Nk, H, D).requires_grad_(True)
+    mt = mask_tensor(kind, c, Nq, Nk)
+    oref = ref_attn(qr, kr, vr, mt)
+    close(o, oref, dtype, atol32=2e-5, atol16=2e-2)
+    s = (qr.transpose(1, 2) @ kr.transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
+    if mt is not None:
+        s = s.masked_fill(~mt, float("-inf"))
+    close(lse, torch.logsumexp(s, -1), torch.float32, atol32=1e-4 if dtype == torch.float32 else 3e-2, rtol32=1e-4)
+    oref.backward(q(do, dtype))
+    dod = dev(do, dtype)
+    dq = torch.empty_like(qd)
+    dkv = torch.empty_like(kvd)
+    dk, dv = dkv[..., : H * D].unflatten(-1, (H, D)), dkv[..., H * D:].unflatten(-1, (H, D))
+    K.attn_bwd(qd, kd, vd, o, dod, lse, dq, dk, dv, m)
+    close(dq, qr.grad, dtype, atol32=5e-5, atol16=4e-2)
+    close(dk, kr.grad, dtype, atol32=5e-5, atol16=4e-2)
+    close(dv, vr.grad, dtype, atol32=5e-5, atol16=4e-2)
+
+
+def test_attention_mask_offsets_and_spike(K):
+    # sliced mask (t_q < t_k, models/brainformer.py:160-162) and a forced running-max jump (online softmax rescale)
+    B, H, Nq, Nk, D = 1, 2, 40, 200, 32
+    qv, kv, vv = rnd(B, Nq, H, D, seed=1), rnd(B, Nk, H, D, seed=2), rnd(B, Nk, H, D, seed=3)
+    kv[0, 150, 0] = 6.0 * qv[0, 7, 0]     # late key strongly aligned with query 7 -> max jumps at the 3rd tile
+    m = K.Mask(2, 8).sliced(256, 256, Nq, Nk)
+    o, lse = K.attn_fwd(dev(qv), dev(kv), dev(vv), m)
+    mt = mask_tensor(2, 8, 256, 256)[-Nq:, -Nk:]
+    close(o, ref_attn(qv, kv, vv, mt), torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("shape", [(1000, 384), (37, 64), (5, 2048)])
+def test_norm(K, dtype, kind, shape):
+    rows, dim = shape
+    x, g, b = rnd(rows, dim, seed=1) * 2 + 0.5, 1 + 0.1 * rnd(dim, seed=2), 0.1 * rnd(dim, seed=3)
+    dy, dres = rnd(rows, dim, seed=4), rnd(rows, dim, seed=5)
+    xr, gr, br = q(x, dtype).requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yref = R.layer_norm(xr, gr, br) if kind == 0 else R.rms_norm(xr, gr)
+    y, mean, rstd = K.norm_fwd(dev(x, dtype), dev(g), dev(b) if kind == 0 else None, 1e-5 if kind == 0 else 1e-6, kind)
+    close(y, yref, dtype, atol32=1e-5)
+    yref.backward(q(dy, dtype))
+    dx, dg, db = K.norm_bwd(dev(dy, dtype), dev(x, dtype), dev(g), mean, rstd, dres=dev(dres, dtype), kind=kind, want_beta=(kind == 0))
+    close(dx, xr.grad + q(dres, dtype), dtype, atol32=2e-5)
+    close(dg, gr.grad, torch.float32, atol32=2e-3 if dtype == torch.float32 else 5e-2, rtol32=1e-3)
+    if kind == 0:
+        close(db, br.grad, torch.float32, atol32=2e-3 if dtype == torch.float32 else 5e-2, rtol32=1e-3)
+
+
+# ----------------------------------------------------------------------------------------------- pointwise
+@pytest.mark.parametrize("dtype", DT)
+def test_rope(K, dtype):
+    B, T, H, D = 2, 50, 3, 16
+    ang = R.rope_angles(D, 64, 10000.0)
+    table = torch.stack([torch.cos(ang), torch.sin(ang)], -1).contiguous()
+    x = rnd(B, T, 3 * H * D, seed=1)
+    xd = dev(x, dtype)
+    K.rope_(xd, 2 * H, D, dev(table), pos_off=64 - T)       # rotate q and k (first 2H heads), leave v
+    want = q(x, dtype).clone()
+    want[..., : 2 * H * D] = R.apply_rope(want[..., : 2 * H * D].reshape(B, T, 2 * H, D), ang).reshape(B, T, -1)
+    close(xd, want, dtype, atol32=1e-6, atol16=2e-2)
+    if dtype == torch.float32:
+        K.rope_(xd, 2 * H, D, dev(table), pos_off=64 - T, conj=True)
+        close(xd, x, dtype, atol32=1e-5)
+    ang3 = torch.stack([ang[3:3 + T], ang[10:10 + T]])
+    t3 = torch.stack([torch.cos(ang3), torch.sin(ang3)], -1).contiguous()
+    yd = dev(x, dtype)
+    K.rope_(yd, 2 * H, D, dev(t3), pos_off=0)
+    want3 = q(x, dtype).clone()
+    want3[..., : 2 * H * D] = R.apply_rope(want3[..., : 2 * H * D].reshape(B, T, 2 * H, D), ang3).reshape(B, T, -1)
+    close(yd, want3, dtype, atol32=1e-6, atol16=2e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_patchify(K, dtype):
+    x = rnd(3, 100, 48, seed=1)
+    tok = K.patchify(dev(x), 25, 32, dtype)
+    want = torch.zeros(3 * 4 * 48, 32)
+    want[:, :25] = R.to_patches(x, 25).reshape(-1, 25)
+    close(tok, q(want, dtype), dtype, atol32=0, rtol32=0, atol16=0, rtol16=0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_swiglu_gelu(K, dtype):
+    rows, H = 333, 96
+    h13, dg = rnd(rows, 2 * H, seed=1), rnd(rows, H, seed=2)
+    hr = q(h13, dtype).requires_grad_(True)
+    gref = R.silu(hr[:, :H]) * hr[:, H:]
+    close(K.swiglu_fwd(dev(h13, dtype)), gref, dtype, atol32=1e-6)
+    gref.backward(q(dg, dtype))
+    close(K.swiglu_bwd(dev(h13, dtype), dev(dg, dtype)), hr.grad, dtype, atol32=2e-6)
+    x = rnd(rows, H, seed=3) * 2
+    xr = q(x, dtype).requires_grad_(True)
+    yref = R.gelu_erf(xr)
+    close(K.gelu_fwd(dev(x, dtype)), yref, dtype, atol32=1e-6)
+    yref.backward(q(dg, dtype))
+    close(K.gelu_bwd(dev(x, dtype), dev(dg, dtype)), xr.grad, dtype, atol32=2e-6)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_cast_pack_add_copy(K, dtype):
+    w = rnd(50, 25, seed=1)
+    d = torch.zeros(50, 32, device="cuda", dtype=dtype)
+    K.cast_pack(dev(w), d)
+    assert torch.equal(d[:, :25].float().cpu(), q(w, dtype)) and float(d[:, 25:].abs().max()) == 0
+    dT = torch.zeros(25, 56, device="cuda", dtype=dtype)
+    K.cast_pack(dev(w), dT, transpose=True)
+    assert torch.equal(dT[:, :50].float().cpu(), q(w, dtype).t())
+    a, b = rnd(1000, seed=2), rnd(1000, seed=3)
+    close(K.add(dev(a, dtype), dev(b, dtype)), q(a, dtype) + q(b, dtype), dtype, atol32=0, atol16=2e-2)
+    assert torch.equal(K.cast(dev(a), dtype).float().cpu(), q(a, dtype))
+    src = dev(rnd(6, 40, seed=4), dtype)
+    dst = torch.zeros(6, 64, device="cuda", dtype=dtype)
+    K.copy2d(src[:, 8:24], dst[:, 32:48])
+    assert torch.equal(dst[:, 32:48], src[:, 8:24])
+
+
+# ----------------------------------------------------------------------------------------------- losses / optimizer
+@pytest.mark.parametrize("dtype", DT)
+def test_l1_mse(K, dtype):
+    p, t = rnd(32, 32, 128, seed=1), rnd(32, 32, 128, seed=2)
+    go = torch.tensor([0.5], device="cuda")
+    for sq in (False, True):
+        pr = q(p, dtype).requires_grad_(True)
+        d = pr - q(t, dtype)
+        ref = (d * d).mean() if sq else d.abs().mean()
+        close(K.l1_loss_fwd(dev(p, dtype), dev(t, dtype), sq)[0], ref, torch.float32, atol32=1e-5)
+        (0.5 * ref).backward()
+        close(K.l1_loss_bwd(dev(p, dtype), dev(t, dtype), go, sq), pr.grad, dtype, atol32=1e-9, rtol32=1e-5, atol16=1e-7, rtol16=1e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("V", [300, 50257])
+def test_cross_entropy(K, dtype, V):
+    rows = 21
+    lg = rnd(rows, V, seed=1) * 2
+    tg = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2))
+    tg[3] = -100
+    tg[20] = -100
+    lr_ = q(lg, dtype).requires_grad_(True)
+    ref = R.cross_entropy(lr_, tg)
+    loss2, lse = K.ce_loss_fwd(dev(lg, dtype), dev(tg))
+    close(loss2[0], ref, torch.float32, atol32=2e-5)
+    assert float(loss2[1]) == rows - 2
+    ref.backward()
+    go = torch.ones(1, device="cuda")
+    dl = K.ce_loss_bwd(dev(lg, dtype), dev(tg), lse, loss2, go, torch.empty(rows, V, device="cuda", dtype=dtype))
+    close(dl, lr_.grad, dtype, atol32=1e-7, rtol32=1e-4, atol16=1e-3, rtol16=2e-2)
+
+
+def test_adamw_matches_reference_trajectory(K, golden):
+    z = golden("ops")
+    p = dev(torch.from_numpy(z["adamw_p0"]).clone())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i in range(3):
+        g = dev(torch.from_numpy(z["adamw_g"][i]).clone())
+        K.adamw_step_(p, g, m, v, i + 1, float(z["adamw_lrs"][i]), weight_decay=1e-5, clip=1.0, zero_grad=(i == 1))
+        np.testing.assert_allclose(p.cpu().numpy(), z["adamw_traj"][i], rtol=2e-6, atol=2e-7)
+        assert (float(g.abs().max()) == 0.0) == (i == 1)
+    # grad_scale (DP mean) and no-clip path against the oracle formula
+    p0, g0 = rnd(1001, seed=1), rnd(1001, seed=2) * 3
+    pr, mr, vr = RT.adamw_step(p0, g0 * 0.25, torch.zeros(1001), torch.zeros(1001), 1, 1e-3, 1e-5)
+    pd, md, vd = dev(p0.clone()), torch.zeros(1001, device="cuda"), torch.zeros(1001, device="cuda")
+    K.adamw_step_(pd, dev(g0.clone()), md, vd, 1, 1e-3, weight_decay=1e-5, clip=0.0, grad_scale=0.25)
+    torch.testing.assert_close(pd.cpu(), pr, rtol=2e-6, atol=2e-7)
+    torch.testing.assert_close(vd.cpu(), vr, rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gpt_embed(K, dtype):
+    B, tc, tw, d, V = 3, 5, 9, 64, 211
+    idx = torch.randint(0, V, (B, tw), generator=torch.Generator().manual_seed(1))
+    prefix, wte, wpe = rnd(B, tc, d, seed=2), rnd(V, d, seed=3), rnd(32, d, seed=4)
+    out = K.gpt_embed_fwd(dev(idx), dev(prefix, dtype), dev(wte), dev(wpe), dtype)
+    want = torch.cat([q(prefix, dtype), wte[idx]], 1) + wpe[: tc + tw]
+    close(out, want, dtype, atol32=1e-6, atol16=3e-2)
+    out0 = K.gpt_embed_fwd(dev(idx), None, dev(wte), dev(wpe), dtype)
+    close(out0, wte[idx] + wpe[:tw], dtype, atol32=1e-6, atol16=3e-2)
+    dout = rnd(B, tc + tw, d, seed=5)
+    dw = torch.zeros(V, d, device="cuda")
+    K.gpt_embed_bwd_wte(dev(idx), dev(dout, dtype), dw, tc)
+    ref = torch.zeros(V, d)
+    ref.index_put_((idx.reshape(-1),), q(dout, dtype)[:, tc:].reshape(-1, d), accumulate=True)
+    close(dw, ref, torch.float32, atol32=1e-5)
+
+
+def test_errors_are_loud(K):
+    from frankenstein_amd._lib import FrankenHipError
+    a = torch.zeros(8, 12, device="cuda")   # K=12 fp32 ok (multiple of 4)
+    w = torch.zeros(8, 12, device="cuda")
+    K.gemm_nt(a, w)
+    with pytest.raises(FrankenHipError, match="multiples"):
+        K.gemm_nt(torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16), torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16))
+    with pytest.raises(FrankenHipError, match="head_dim"):
+        K.attn_fwd(torch.zeros(1, 8, 1, 24, device="cuda"), torch.zeros(1, 8, 1, 24, device="cuda"), torch.zeros(1, 8, 1, 24, device="cuda"))
