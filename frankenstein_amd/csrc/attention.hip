@@ -41,7 +41,7 @@ template <typename T, int D> struct AT {
   static constexpr int ES = sizeof(T);
   static constexpr int RB = D * ES;                 // bytes per head row
   static constexpr int CPR = RB / 16;               // 16-byte chunks per row
-  static constexpr int KSTEPS = D / 16;             // k16 steps across the head dim
+  static constexpr int KSTEPS = (D + 15) / 16;      // k16 steps across the head dim (D = 8: upper half-slots are zero)
   static constexpr int DT = (D + 31) / 32;          // 32-row tiles of O^T / dK^T / dV^T
   static constexpr int DPAD = DT * 32;
   static constexpr int RSTRIDE = DPAD * ES + 16;    // row-read / dual-use LDS image stride (padded: conflict-free b128)
@@ -169,15 +169,15 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
   const int qrow = q0 + wave * 32 + li;
   const bool q_ok = qrow < p.Nq;
 
-  if constexpr (C::DPAD != D) {   // zero the padded columns of the V images once (never restaged)
-    for (int i = tid; i < 2 * VIMG / 4; i += NT) reinterpret_cast<float*>(vimg(0))[i] = 0.0f;
+  if constexpr (C::DPAD != D) {   // zero the padded columns of the K/V images once (never restaged)
+    for (int i = tid; i < (2 * KIMG + 2 * VIMG) / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
     __syncthreads();
   }
 
   Frag<T> qf[C::KSTEPS];
 #pragma unroll
   for (int s = 0; s < C::KSTEPS; ++s) {
-    if (q_ok) frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+    if (q_ok && 16 * s + 8 * lh < D) frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
     else frag_zero<T>(qf[s]);
   }
 
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   Frag<T> qf[C::KSTEPS], gf[C::KSTEPS];
 #pragma unroll
   for (int s = 0; s < C::KSTEPS; ++s) {
-    if (q_ok) {
+    if (q_ok && 16 * s + 8 * lh < D) {
       frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
       frag_load_contig<T>(gf[s], Gp + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
     } else {
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs p) {
   Frag<T> kf[C::KSTEPS], vf[C::KSTEPS];
 #pragma unroll
   for (int s = 0; s < C::KSTEPS; ++s) {
-    if (k_ok) {
+    if (k_ok && 16 * s + 8 * lh < D) {
       frag_load_contig<T>(kf[s], Kp + (int64_t)krow * p.k_rs + 16 * s + 8 * lh);
       frag_load_contig<T>(vf[s], Vp + (int64_t)krow * p.v_rs + 16 * s + 8 * lh);
     } else {
@@ -596,8 +596,8 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
 int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D, int dtype, int mask_kind,
                  int64_t mask_c, const int64_t* strides, int nstr) {
   FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "%s: bad dtype %d", name, dtype);
-  FK_CHECK_ARG(D == 16 || D == 32 || D == 64 || (D == 128 && dtype == FK_BF16),
-               "%s: head_dim %lld unsupported (16/32/64, 128 for bf16)", name, (long long)D);
+  FK_CHECK_ARG(D == 8 || D == 16 || D == 32 || D == 64 || (D == 128 && dtype == FK_BF16),
+               "%s: head_dim %lld unsupported (8/16/32/64, 128 for bf16)", name, (long long)D);
   FK_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B < 65536 && H < 65536 && Nq < (1LL << 30) && Nk < (1LL << 30),
                "%s: bad shape B=%lld H=%lld Nq=%lld Nk=%lld", name, (long long)B, (long long)H, (long long)Nq, (long long)Nk);
   FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL,
@@ -613,6 +613,7 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
   do {                                                                                        \
     if (dtype == FK_BF16) {                                                                   \
       switch (D) {                                                                            \
+        case 8: FN<bf16_t, 8>(args, stream); break;                                           \
         case 16: FN<bf16_t, 16>(args, stream); break;                                         \
         case 32: FN<bf16_t, 32>(args, stream); break;                                         \
         case 64: FN<bf16_t, 64>(args, stream); break;                                         \
@@ -620,6 +621,7 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
       }                                                                                       \
     } else {                                                                                  \
       switch (D) {                                                                            \
+        case 8: FN<float, 8>(args, stream); break;                                            \
         case 16: FN<float, 16>(args, stream); break;                                          \
         case 32: FN<float, 32>(args, stream); break;                                          \
         default: FN<float, 64>(args, stream); break;                                          \

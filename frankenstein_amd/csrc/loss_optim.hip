@@ -120,8 +120,8 @@ __global__ void ce_bwd_kernel(const T* logits, int64_t ld, const int64_t* target
 }
 
 // ---- AdamW --------------------------------------------------------------------------------------------
-__global__ void adamw_kernel(float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                             float wd, float bc1, float sqrt_bc2, float clip, float gscale, int zero_grad) {
+__global__ void adamw_kernel(float* p, float* g, float* m, float* v, int64_t n, float lr, float omb1, float b2, float omb2,
+                             float eps, float wd, float bc1, float sqrt_bc2, float clip, float gscale, int zero_grad) {
   const int64_t nv = n >> 2;
   const float step_size = lr / bc1, decay = 1.0f - lr * wd;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
@@ -132,8 +132,8 @@ __global__ void adamw_kernel(float* p, float* g, float* m, float* v, int64_t n, 
       float gg = gv[j] * gscale;
       if (clip > 0.0f) gg = fminf(fmaxf(gg, -clip), clip);
       pv[j] *= decay;
-      mv[j] = b1 * mv[j] + (1.0f - b1) * gg;
-      vv[j] = b2 * vv[j] + (1.0f - b2) * gg * gg;
+      mv[j] += omb1 * (gg - mv[j]);                    // exp_avg.lerp_(grad, 1 - beta1)
+      vv[j] = b2 * vv[j] + omb2 * gg * gg;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
       pv[j] -= step_size * (mv[j] / (sqrtf(vv[j]) / sqrt_bc2 + eps));
     }
     reinterpret_cast<f32x4*>(p)[i] = pv;
@@ -146,7 +146,7 @@ __global__ void adamw_kernel(float* p, float* g, float* m, float* v, int64_t n, 
     float gg = g[i] * gscale;
     if (clip > 0.0f) gg = fminf(fmaxf(gg, -clip), clip);
     float pv = p[i] * decay;
-    const float mv = b1 * m[i] + (1.0f - b1) * gg, vv = b2 * v[i] + (1.0f - b2) * gg * gg;
+    const float mv = m[i] + omb1 * (gg - m[i]), vv = b2 * v[i] + omb2 * gg * gg;
     pv -= step_size * (mv / (sqrtf(vv) / sqrt_bc2 + eps));
     p[i] = pv; m[i] = mv; v[i] = vv;
     if (zero_grad) g[i] = 0.0f;
@@ -228,8 +228,8 @@ int fk_adamw_step(float* p, float* g, float* m, float* v, int64_t n, double lr, 
   FK_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "fk_adamw_step: bad arguments");
   FK_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "fk_adamw_step: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 4096)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)beta1,
-                     (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2), (float)clip, (float)grad_scale, zero_grad);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 4096)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2), (float)clip, (float)grad_scale, zero_grad);
   FK_CHECK_LAUNCH("fk_adamw_step");
   return FK_OK;
 }

@@ -54,12 +54,13 @@ class _Shadow:
 _SHADOWS: dict = {}
 
 
-def shadow(params: Sequence[Tensor], transpose: bool = False, pad_k: int = 0) -> Tensor:
-    """Compute-dtype copy of cat(params, dim=0) ([sum N, K]); transposed -> [K, sum N]; pad_k zero-pads K.
-    1-D params (biases) are concatenated as vectors.  Rebuilt only when a master changed."""
+def shadow(params: Sequence[Tensor], transpose: bool = False, pad_k: int = 0, pad_n: int = 0) -> Tensor:
+    """Compute-dtype copy of cat(params, dim=0) ([sum N, K]); transposed -> [K, sum N]; pad_k / pad_n zero-pad
+    the K / N extents (16-byte GEMM operand alignment).  1-D params (biases) are concatenated as vectors.
+    Rebuilt only when a master changed (tensor version counter) or the optimizer bumped the epoch."""
     dt = _COMPUTE_DTYPE
-    key = (tuple(id(p) for p in params), transpose, pad_k)
-    stamp = (_EPOCH, dt, tuple(p._version for p in params), params[0].device, tuple(p.data_ptr() for p in params))
+    key = (tuple((p.data_ptr(), tuple(p.shape)) for p in params), transpose, pad_k, pad_n, dt)
+    stamp = (_EPOCH, tuple(p._version for p in params))
     ent = _SHADOWS.get(key)
     if ent is None:
         ent = _SHADOWS[key] = _Shadow()
@@ -82,11 +83,12 @@ def shadow(params: Sequence[Tensor], transpose: bool = False, pad_k: int = 0) ->
         Kd = p0.shape[1]
         kp = max(Kd, pad_k)
         n = sum(p.shape[0] for p in params)
-        if dt == torch.float32 and len(params) == 1 and not transpose and kp == Kd and p0.is_contiguous():
+        npad = max(n, pad_n)
+        if dt == torch.float32 and len(params) == 1 and not transpose and kp == Kd and npad == n and p0.is_contiguous():
             out = p0.detach()
         else:
-            shape = (kp, n) if transpose else (n, kp)
-            out = (torch.zeros if kp != Kd else torch.empty)(shape, dtype=dt, device=p0.device)
+            shape = (kp, npad) if transpose else (npad, kp)
+            out = (torch.zeros if (kp != Kd or npad != n) else torch.empty)(shape, dtype=dt, device=p0.device)
             off = 0
             for p in params:
                 src = p.detach()
@@ -320,29 +322,22 @@ class NormLinear(torch.autograd.Function):
         dy2 = dy.contiguous().view(x2.shape[0], -1)
         if dy2.dtype != x2.dtype:
             dy2 = K.cast(dy2, x2.dtype)
-        dh = K.gemm_nt(dy2, shadow([w], transpose=True))
-        dw = K.gemm_tn(dy2, h) if _tn_ok(dy2, h) else _gemm_tn_padded(dy2, h)
+        nout = dy2.shape[1]
+        vec = 8 if dy2.dtype == torch.bfloat16 else 4
+        npad = (nout + vec - 1) // vec * vec
+        if npad != nout:   # e.g. vocab 50257: zero-pad the reduction dim of the dgrad / the rows of the wgrad operand
+            dyp = torch.zeros((dy2.shape[0], npad), dtype=dy2.dtype, device=dy2.device)
+            K.copy2d(dy2, dyp[:, :nout])
+        else:
+            dyp = dy2
+        dh = K.gemm_nt(dyp, shadow([w], transpose=True, pad_n=npad))
+        dw = K.gemm_tn(dyp, h)[:nout]
         db = K.colsum(dy2) if has_b else None
         if ctx.has_ln:
             dx, dg, dbe = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, want_beta=has_lnb)
         else:
             dx, dg, dbe = dh, None, None
         return dx.view(shp), dg, dbe, dw, db, None, None
-
-
-def _tn_ok(a: Tensor, b: Tensor) -> bool:
-    vec = 8 if a.dtype == torch.bfloat16 else 4
-    return a.shape[1] % vec == 0 and b.shape[1] % vec == 0
-
-
-def _gemm_tn_padded(a: Tensor, b: Tensor) -> Tensor:
-    """dW for an output width that is not a multiple of the 16-byte vector (e.g. vocab 50257): pad the dy
-    operand's columns with zeros into a scratch copy (head-sized; off the encoder's critical path)."""
-    vec = 8 if a.dtype == torch.bfloat16 else 4
-    n1 = (a.shape[1] + vec - 1) // vec * vec
-    ap = torch.zeros((a.shape[0], n1), dtype=a.dtype, device=a.device)
-    K.copy2d(a, ap[:, :a.shape[1]])
-    return K.gemm_tn(ap, b)[:a.shape[1]]
 
 
 class LayerNormFn(torch.autograd.Function):

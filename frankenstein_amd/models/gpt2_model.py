@@ -1,0 +1,253 @@
+"""MI355X-native GPT-2 decoder with the reference's ``models/gpt2_model.py`` surface: ``GPTConfig``,
+``GPT(config).forward(idx, prefix=None, targets=None) -> (loss, logits)`` with brain-feature *prefix*
+embeddings, tied ``lm_head``/``wte``, and the same state-dict keys.  Forward/backward run on the HIP
+kernels (fused c_attn GEMM + causal flash attention + GELU MLP + CE).
+
+Reference map: LayerNorm models/gpt2_model.py:18-27, CausalSelfAttention :29-76, MLP :78-92,
+Block :94-106, GPTConfig :108-116, GPT :118-216 (+ crop_block_size :218-227, from_pretrained :229-284,
+configure_optimizers :286-310, estimate_mfu :312-326, generate :328-353).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from .. import kernels as K
+from ..kernels import MASK_CAUSAL, Mask
+from .brainformer import Linear, _prep
+
+CAUSAL = Mask(MASK_CAUSAL)
+
+
+class LayerNorm(nn.Module):
+    """LayerNorm with an optional bias (eps 1e-5)."""
+
+    def __init__(self, ndim, bias):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(ndim))
+        self.bias = nn.Parameter(torch.zeros(ndim)) if bias else None
+        self.eps = 1e-5
+
+    def forward(self, input):
+        return E.LayerNormFn.apply(_prep(input), self.weight, self.bias, self.eps, K.NORM_LAYER)
+
+
+class CausalSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0
+        self.c_attn = Linear(config.n_embd, 3 * config.n_embd, bias=config.bias)
+        self.c_proj = Linear(config.n_embd, config.n_embd, bias=config.bias)
+        self.n_head = config.n_head
+        self.n_embd = config.n_embd
+        self.dropout = config.dropout
+
+    def branch(self, x, ln, residual: bool):
+        if self.dropout and self.training:
+            raise NotImplementedError("attention/residual dropout > 0 is not implemented in the fused kernels")
+        spec = (self.n_head, self.n_embd // self.n_head, CAUSAL, None, residual, 0.0 if ln is None else ln.eps)
+        return E.AttnBranch.apply(x, None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                  self.c_proj.weight, self.c_proj.bias, self.c_attn.bias, spec, self.c_attn.weight)
+
+    def forward(self, x):
+        return self.branch(_prep(x), None, False)
+
+
+class MLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.c_fc = Linear(config.n_embd, 4 * config.n_embd, bias=config.bias)
+        self.gelu = nn.GELU()
+        self.c_proj = Linear(4 * config.n_embd, config.n_embd, bias=config.bias)
+        self.dropout = nn.Dropout(config.dropout)
+
+    def branch(self, x, ln, residual: bool):
+        if self.dropout.p and self.training:
+            raise NotImplementedError("MLP dropout > 0 is not implemented in the fused kernels")
+        return E.MlpBranch.apply(x, None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                 self.c_fc.weight, self.c_fc.bias, None, self.c_proj.weight, self.c_proj.bias,
+                                 (residual, 0.0 if ln is None else ln.eps))
+
+    def forward(self, x):
+        return self.branch(_prep(x), None, False)
+
+
+class Block(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.ln_1 = LayerNorm(config.n_embd, bias=config.bias)
+        self.attn = CausalSelfAttention(config)
+        self.ln_2 = LayerNorm(config.n_embd, bias=config.bias)
+        self.mlp = MLP(config)
+
+    def forward(self, x):
+        x = self.attn.branch(_prep(x), self.ln_1, True)
+        return self.mlp.branch(x, self.ln_2, True)
+
+
+@dataclass
+class GPTConfig:
+    block_size: int = 1024
+    vocab_size: int = 50304
+    n_layer: int = 12
+    n_head: int = 12
+    n_embd: int = 768
+    dropout: float = 0.0
+    bias: bool = True
+
+
+class _GptEmbed(torch.autograd.Function):
+    """x[b, t] = (t < t_ctx ? prefix[b, t] : wte[idx[b, t - t_ctx]]) + wpe[t]   (models/gpt2_model.py:183-196)."""
+
+    @staticmethod
+    def forward(ctx, idx, prefix, wte, wpe):
+        out = K.gpt_embed_fwd(idx.contiguous(), prefix, wte.detach(), wpe.detach(), E.compute_dtype())
+        ctx.t_ctx = 0 if prefix is None else prefix.shape[1]
+        ctx.shapes = (wte.shape, wpe.shape)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        (idx,) = ctx.saved_tensors
+        dx = dx.contiguous()
+        B, t_full, d = dx.shape
+        t_ctx = ctx.t_ctx
+        dprefix = None
+        if t_ctx:
+            dprefix = torch.empty((B, t_ctx, d), dtype=dx.dtype, device=dx.device)
+            K.copy2d(dx.view(B, t_full * d)[:, :t_ctx * d], dprefix.view(B, t_ctx * d))
+        dwte = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dx.device)
+        K.gpt_embed_bwd_wte(idx.contiguous(), dx, dwte, t_ctx)
+        dwpe = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dx.device)
+        K.colsum(dx.view(B, t_full * d), out=dwpe.view(-1)[: t_full * d])
+        return None, dprefix, dwte, dwpe
+
+
+class GPT(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        assert config.vocab_size is not None
+        assert config.block_size is not None
+        self.config = config
+        self.transformer = nn.ModuleDict(dict(
+            wte=nn.Embedding(config.vocab_size, config.n_embd),
+            wpe=nn.Embedding(config.block_size, config.n_embd),
+            drop=nn.Dropout(config.dropout),
+            h=nn.ModuleList([Block(config) for _ in range(config.n_layer)]),
+            ln_f=LayerNorm(config.n_embd, bias=config.bias),
+        ))
+        self.lm_head = Linear(config.n_embd, config.vocab_size, bias=False)
+        self.transformer.wte.weight = self.lm_head.weight   # weight tying
+        self.apply(self._init_weights)
+        for pn, p in self.named_parameters():
+            if pn.endswith('c_proj.weight'):
+                torch.nn.init.normal_(p, mean=0.0, std=0.02 / math.sqrt(2 * config.n_layer))
+        print("number of parameters: %.2fM" % (self.get_num_params() / 1e6,))
+
+    def get_num_params(self, non_embedding=True):
+        n_params = sum(p.numel() for p in self.parameters())
+        if non_embedding:
+            n_params -= self.transformer.wpe.weight.numel()
+        return n_params
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def _init_weights(self, module):
+        if isinstance(module, nn.Linear):
+            torch.nn.init.normal_(module.weight, mean=0.0, std=0.02)
+            if module.bias is not None:
+                torch.nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.Embedding):
+            torch.nn.init.normal_(module.weight, mean=0.0, std=0.02)
+
+    def forward(self, idx, prefix=None, targets=None):
+        t_words = idx.size(1)
+        if self.config.dropout and self.training:
+            raise NotImplementedError("embedding dropout > 0 is not implemented in the fused kernels")
+        if prefix is not None:
+            prefix = _prep(prefix)
+        x = _GptEmbed.apply(idx, prefix, self.transformer.wte.weight, self.transformer.wpe.weight)
+        for block in self.transformer.h:
+            x = block(x)
+        x = _prep(x[:, -t_words:])            # keep only the text positions (strided-copy kernel)
+        ln = self.transformer.ln_f
+        if targets is not None:
+            logits = E.NormLinear.apply(x, ln.weight, ln.bias, self.lm_head.weight, None, ln.eps, False)
+            # CE(logits[:, :-1], targets[:, 1:], ignore_index=-100) == CE over all rows with the targets shifted
+            # left and the last position ignored (ignored rows contribute nothing to the mean)
+            shifted = torch.full_like(targets, -100)
+            shifted[:, :-1] = targets[:, 1:]
+            loss = E.cross_entropy(logits, shifted, -100)
+        else:
+            last = _prep(x[:, -1:, :])
+            logits = E.NormLinear.apply(last, ln.weight, ln.bias, self.lm_head.weight, None, ln.eps, False)
+            loss = None
+        return loss, logits
+
+    def crop_block_size(self, block_size):
+        assert block_size <= self.config.block_size
+        self.config.block_size = block_size
+        self.transformer.wpe.weight = nn.Parameter(self.transformer.wpe.weight[:block_size])
+
+    @classmethod
+    def from_pretrained(cls, model_type, override_args=None):
+        """Load OpenAI GPT-2 weights through HF transformers (needs network / a local HF cache)."""
+        sizes = {'gpt2': (12, 12, 768), 'gpt2-medium': (24, 16, 1024), 'gpt2-large': (36, 20, 1280),
+                 'gpt2-xl': (48, 25, 1600)}
+        assert model_type in sizes
+        override_args = override_args or {}
+        assert all(k == 'dropout' for k in override_args)
+        from transformers import GPT2LMHeadModel
+        n_layer, n_head, n_embd = sizes[model_type]
+        config = GPTConfig(block_size=1024, vocab_size=50257, n_layer=n_layer, n_head=n_head, n_embd=n_embd,
+                           dropout=override_args.get('dropout', 0.0), bias=True)
+        model = cls(config)
+        sd = model.state_dict()
+        hf = GPT2LMHeadModel.from_pretrained(model_type).state_dict()
+        conv1d = ('attn.c_attn.weight', 'attn.c_proj.weight', 'mlp.c_fc.weight', 'mlp.c_proj.weight')
+        with torch.no_grad():
+            for k, v in hf.items():
+                if k.endswith('.attn.masked_bias') or k.endswith('.attn.bias'):
+                    continue
+                src = v.t() if k.endswith(conv1d) else v   # HF stores Conv1D weights transposed
+                assert sd[k].shape == src.shape, (k, sd[k].shape, src.shape)
+                sd[k].copy_(src)
+        return model
+
+    def configure_optimizers(self, weight_decay, learning_rate, betas, device_type):
+        decay = [p for _, p in self.named_parameters() if p.requires_grad and p.dim() >= 2]
+        nodecay = [p for _, p in self.named_parameters() if p.requires_grad and p.dim() < 2]
+        groups = [{'params': decay, 'weight_decay': weight_decay}, {'params': nodecay, 'weight_decay': 0.0}]
+        return torch.optim.AdamW(groups, lr=learning_rate, betas=betas)
+
+    def estimate_mfu(self, fwdbwd_per_iter, dt, peak_flops=2.5e15):
+        """model flops utilisation vs the MI355X dense bf16 MFMA peak (the reference hard-codes A100 312 TF)."""
+        N = self.get_num_params()
+        cfg = self.config
+        L, H, Q, T = cfg.n_layer, cfg.n_head, cfg.n_embd // cfg.n_head, cfg.block_size
+        flops_per_iter = (6 * N + 12 * L * H * Q * T) * T * fwdbwd_per_iter
+        return flops_per_iter / dt / peak_flops
+
+    @torch.no_grad()
+    def generate(self, idx, max_new_tokens, prefix=None, temperature=1.0, top_k=None):
+        """Sampling loop around the kernel forward (full re-forward per token like the reference; host-side glue)."""
+        for _ in range(max_new_tokens):
+            _, logits = self(idx, prefix=prefix)
+            logits = logits[:, -1, :].float() / temperature
+            if top_k is not None:
+                v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+                logits[logits < v[:, [-1]]] = -float('Inf')
+            probs = torch.softmax(logits, dim=-1)
+            idx = torch.cat((idx, torch.multinomial(probs, num_samples=1)), dim=1)
+        return idx

@@ -137,6 +137,8 @@ ATTN_CASES = [
     (1, 4, 32, 300, 64, 0, 0),
     (2, 4, 128, 128, 16, 2, 16),
     (1, 2, 8, 8, 16, 0, 0),
+    (3, 4, 8, 8, 8, 0, 0),
+    (2, 4, 40, 128, 8, 2, 16),
     (1, 2, 512, 512, 64, 2, 256),
     (1, 1, 320, 320, 32, 1, 0),
 ]

@@ -1,0 +1,235 @@
+"""Model-level parity on the MI355X: the drop-in modules (frankenstein_amd.models.*) running on the HIP
+kernels vs (a) the golden vectors produced by the actual reference and (b) the CPU oracle, on the same
+seeded inputs/weights.  fp32 parity mode: logits within 1e-3 (north star); bf16 mode: drift reported
+against a loose bound."""
+import numpy as np
+import pytest
+import torch
+
+import frankenstein_amd as fa
+from frankenstein_amd import synth
+from oracle import ref_models as R
+from tests import cases as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _fp32_mode():
+    fa.set_compute_dtype("fp32")
+    yield
+    fa.set_compute_dtype("bf16")
+
+
+def load_synth(model, skip=("attn_mask",)):
+    sd = model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if v is not None}
+    st = synth.make_state(shapes, synth.SEED_WEIGHTS, skip)
+    for k in list(st):
+        if k.endswith("lm_head.weight"):
+            st[k] = st[k.replace("lm_head.weight", "transformer.wte.weight")]
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=False)
+    assert all(m.endswith("attn_mask") for m in missing), missing
+    assert not unexpected
+    return model.cuda()
+
+
+def mk_bf(cfgo, cls):
+    from frankenstein_amd.models import brainformer as bf
+    e = cfgo.encoder
+    enc = bf.MAEConfig(window_size=e.window_size, n_electrodes=e.n_electrodes, patch_size=e.patch_size, dim=e.dim,
+                       n_layers=e.n_layers, head_dim=e.head_dim, hidden_dim=e.hidden_dim, n_heads=e.n_heads,
+                       n_kv_heads=e.n_kv_heads)
+    cfg = bf.Config(encoder=enc, n_output_tokens=cfgo.n_output_tokens, output_dim=cfgo.output_dim, dim=cfgo.dim,
+                    n_layers=cfgo.n_layers, head_dim=cfgo.head_dim, hidden_dim=cfgo.hidden_dim, n_heads=cfgo.n_heads,
+                    n_kv_heads=cfgo.n_kv_heads)
+    return load_synth(cls(cfg))
+
+
+def mk_gpt(cfgo):
+    from frankenstein_amd.models import gpt2_model as g2
+    return g2.GPT(g2.GPTConfig(block_size=cfgo.block_size, vocab_size=cfgo.vocab_size, n_layer=cfgo.n_layer,
+                               n_head=cfgo.n_head, n_embd=cfgo.n_embd, dropout=0.0, bias=cfgo.bias))
+
+
+def named_grads(model):
+    seen, out = set(), {}
+    for k, p in model.named_parameters():
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        out[k] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().float().cpu()
+    return out
+
+
+def check_full_grads(model, z, rtol=1e-3, atol=2e-5):
+    g = named_grads(model)
+    keys = [k for k in z.files if k.startswith("grad/") and not k.endswith("lm_head.weight")]
+    assert keys
+    for k in keys:
+        np.testing.assert_allclose(g[k[5:]].numpy(), z[k], rtol=rtol, atol=atol, err_msg=k)
+
+
+def check_grad_rows(model, z, rtol=2e-3, atol=2e-4):
+    names, rows = C.summarize_rows(named_grads(model))
+    want = {str(n).replace("lm_head.weight", "transformer.wte.weight"): r for n, r in zip(z["grad_names"], z["grad_rows"])}
+    for n, r in zip(names, rows):
+        np.testing.assert_allclose(r, want[n], rtol=rtol, atol=atol, err_msg=n)
+
+
+def test_bf_l1_small_fp32(golden):
+    from frankenstein_amd.models import brainformer as bf
+    z = golden("bf_l1_small")
+    cfgo, x, tgt = C.bf_l1_small()
+    m = mk_bf(cfgo, bf.BrainFormer)
+    loss, pred = m(x.cuda(), tgt.cuda())
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    np.testing.assert_allclose(pred.float().cpu().detach().numpy(), z["pred"], atol=1e-4)
+    np.testing.assert_allclose(m.encoder(x.cuda()).float().cpu().detach().numpy(), z["enc_out"], atol=1e-4)
+    loss.backward()
+    check_full_grads(m, z)
+    none_loss, pred2 = m(x.cuda())
+    assert none_loss is None and torch.equal(pred2, pred)
+
+
+def test_bf_ce_small_fp32(golden):
+    from frankenstein_amd.models.notebook_models import BrainFormerCE
+    z = golden("bf_ce_small")
+    cfgo, x, tok = C.bf_ce_small()
+    m = mk_bf(cfgo, BrainFormerCE)
+    loss, logits = m(x.cuda(), tok.cuda())
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    np.testing.assert_allclose(logits.float().cpu().detach().numpy(), z["logits"], atol=1e-4)
+    loss.backward()
+    check_full_grads(m, z)
+
+
+@pytest.mark.parametrize("bias", [True, False])
+def test_gpt_small_fp32(golden, bias):
+    z = golden(f"gpt_small_bias{int(bias)}")
+    cfgo, prefix, tk, idx = C.gpt_small(bias)
+    g = load_synth(mk_gpt(cfgo))
+    pf = prefix.cuda().requires_grad_(True)
+    loss, logits = g(idx.cuda(), prefix=pf, targets=tk.cuda())
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    np.testing.assert_allclose(logits.float().cpu().detach().numpy(), z["logits"], atol=1e-4)
+    loss.backward()
+    np.testing.assert_allclose(pf.grad.cpu().numpy(), z["prefix_grad"], rtol=1e-3, atol=1e-6)
+    check_full_grads(g, z)
+    _, last = g(idx.cuda(), prefix=prefix.cuda(), targets=None)
+    np.testing.assert_allclose(last.float().cpu().detach().numpy(), z["last_logits"], atol=1e-4)
+    loss2, logits2 = g(idx.cuda(), prefix=None, targets=tk.cuda())
+    assert abs(float(loss2) - float(z["loss_noprefix"])) < 1e-5
+    np.testing.assert_allclose(logits2.float().cpu().detach().numpy(), z["logits_noprefix"], atol=1e-4)
+
+
+def build_franky():
+    from frankenstein_amd.models.notebook_models import BrainEncoder, Franky
+    bcfg, gcfg, x, tok = C.cfg1()
+    from frankenstein_amd.models import brainformer as bf
+    e = bcfg.encoder
+    enc = bf.MAEConfig(window_size=e.window_size, n_electrodes=256, patch_size=25, dim=128, n_layers=2, head_dim=32,
+                       hidden_dim=512, n_heads=4, n_kv_heads=4)
+    cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=128, n_layers=2, head_dim=32, hidden_dim=256,
+                    n_heads=4, n_kv_heads=4)
+    fr = Franky(BrainEncoder(cfg), mk_gpt(gcfg))
+    return load_synth(fr), x, tok
+
+
+def test_cfg1_franky_fp32_logits_within_1e3(golden):
+    """BASELINE.json configs[0]: logits within 1e-3 of the reference CPU path, argmax agreement, loss, grads."""
+    z = golden("cfg1_franky")
+    fr, x, tok = build_franky()
+    feats = fr.brain_model(x.cuda())
+    np.testing.assert_allclose(feats.float().cpu().detach().numpy(), z["features"], atol=1e-3)
+    loss, logits = fr(x.cuda(), tok.cuda())
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    lg = logits.detach().float().cpu()
+    assert float((lg[:, :, :64] - torch.from_numpy(z["logits_head"])).abs().max()) < 1e-3
+    assert float((lg[:, :, -33:] - torch.from_numpy(z["logits_tail"])).abs().max()) < 1e-3
+    np.testing.assert_allclose(torch.logsumexp(lg, -1).numpy(), z["logits_lse"], atol=1e-3)
+    assert np.array_equal(lg.argmax(-1).numpy(), z["logits_argmax"])       # token-level agreement ("WER 0")
+    loss.backward()
+    check_grad_rows(fr, z)
+
+
+def test_cfg1_train_steps_fp32(golden):
+    """two iterations of the reference loop body (lr set, fwd, bwd, clip_grad_value_(1), AdamW) vs the reference."""
+    from frankenstein_amd.utils import train_utils as tu
+    z = golden("cfg1_franky")
+    fr, x, tok = build_franky()
+    cfg = tu.TrainConfig(mixed_precision=False)
+    opt = tu.FusedAdamW(fr, lr=1e-3, weight_decay=cfg.weight_decay, grad_clip=cfg.grad_clip)
+    losses = []
+    for i, lr in enumerate((1e-3, 5e-4)):
+        l = tu.train_step(fr, (x.cuda(), tok.cuda(), None), opt, i, cfg, scheduler=lambda it, lr=lr: lr)
+        losses.append(float(l))
+    np.testing.assert_allclose(losses, z["step_losses"], rtol=1e-4)
+    names, rows = C.summarize_rows({k: p.detach().float().cpu() for k, p in fr.named_parameters()})
+    want = {str(n).replace("lm_head.weight", "transformer.wte.weight"): r for n, r in zip(z["param_names"], z["param_rows"])}
+    for n, r in zip(names, rows):
+        np.testing.assert_allclose(r[2:], want[n][2:], rtol=1e-3, atol=5e-5, err_msg=n)
+        np.testing.assert_allclose(r[:2], want[n][:2], rtol=1e-3, atol=5e-2, err_msg=n)
+    assert float(opt.arena.grad.abs().max()) == 0.0      # zero_grad fused into the step
+
+
+def test_cfg2_b1_fp32(golden):
+    """brainformer-small (6L, d=384, 6 heads x 64, N=6144 tokens) at B=1 against the reference golden."""
+    from frankenstein_amd.models import brainformer as bf
+    z = golden("cfg2_b1")
+    cfgo, x, tgt = C.cfg2(1)
+    m = mk_bf(cfgo, bf.BrainFormer)
+    loss, pred = m(x.cuda(), tgt.cuda())
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    assert float((pred.float().cpu().detach() - torch.from_numpy(z["pred"])).abs().max()) < 1e-3
+    with torch.no_grad():
+        ctx = m.encoder(x.cuda())
+    np.testing.assert_allclose(ctx[0, [0, 1, 255, 256, 3071, 6143]].float().cpu().numpy(), z["enc_rows"], atol=1e-3)
+    loss.backward()
+    check_grad_rows(m, z, rtol=5e-3, atol=5e-4)
+
+
+def test_bf16_drift_small():
+    """bf16 throughput mode vs the fp32 CPU oracle on the small model: bounded drift, same loss to ~1e-2."""
+    from frankenstein_amd.models import brainformer as bf
+    fa.set_compute_dtype("bf16")
+    cfgo, x, tgt = C.bf_l1_small()
+    m = mk_bf(cfgo, bf.BrainFormer)
+    loss, pred = m(x.cuda(), tgt.cuda())
+    sd = C.state(R.brainformer_shapes(cfgo, "to_motion"))
+    rl, rp = R.brainformer_l1(sd, x, tgt, cfgo)
+    assert abs(float(loss) - float(rl)) < 3e-2
+    assert float((pred.float().cpu() - rp).abs().max()) < 0.15
+    loss.backward()
+    g = named_grads(m)
+    assert all(torch.isfinite(v).all() for v in g.values())
+
+
+def test_standalone_modules_match_oracle():
+    """Sub-modules are public API in the notebooks (Encoder, CrossBlock, Block, attention, MLP called directly)."""
+    from frankenstein_amd.models import brainformer as bf
+    cfgo, x, _ = C.bf_l1_small()
+    m = mk_bf(cfgo, bf.BrainFormer)
+    sd = C.state(R.brainformer_shapes(cfgo, "to_motion"))
+    e = cfgo.encoder
+    h = torch.randn(2, 128, 64, generator=torch.Generator().manual_seed(3))
+    blk = m.encoder.transformer.h[0]
+    mask, rope = m.encoder.attn_mask, m.encoder.rope_cache
+    bf.register_mask(mask, bf.Mask(bf.MASK_BLOCK_CAUSAL, e.n_electrodes))
+    ang = R.rope_angles(e.head_dim, 128, 10000.0)
+    want = R.block(sd, "encoder.transformer.h.0.", h, e, R.block_causal_mask(128, 16), ang)
+    torch.testing.assert_close(blk(h.cuda(), attn_mask=mask, rope=rope).cpu(), want, atol=1e-4, rtol=1e-4)
+    want = R.self_attention(sd, "encoder.transformer.h.0.attn.", h, 4, 16, R.block_causal_mask(128, 16), ang)
+    torch.testing.assert_close(blk.attn(h.cuda(), mask, rope).cpu(), want, atol=1e-4, rtol=1e-4)
+    want = R.swiglu_mlp(sd, "encoder.transformer.h.0.mlp.", h)
+    torch.testing.assert_close(blk.mlp(h.cuda()).cpu(), want, atol=1e-4, rtol=1e-4)
+    # shorter sequence: mask[..., -t:, -t:] and rope[-t:] slicing (models/brainformer.py:80,160-162)
+    hs = h[:, :48]
+    want = R.block(sd, "encoder.transformer.h.0.", hs, e, R.block_causal_mask(128, 16), ang)
+    torch.testing.assert_close(blk(hs.cuda().contiguous(), attn_mask=mask, rope=rope).cpu(), want, atol=1e-4, rtol=1e-4)
+    with pytest.raises(NotImplementedError):
+        blk(h.cuda(), attn_mask=torch.ones(128, 128, dtype=torch.bool, device="cuda"), rope=rope)
+    q = torch.randn(2, 8, 64, generator=torch.Generator().manual_seed(4))
+    cb = m.perceiver.h[0]
+    want = R.cross_attention(sd, "perceiver.h.0.cross_attn.", q, h, 4, 8)
+    torch.testing.assert_close(cb.cross_attn(q.cuda(), h.cuda()).cpu(), want, atol=1e-4, rtol=1e-4)
