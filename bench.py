@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: brainformer-small training throughput on MI355X.
+
+Workload (BASELINE.json configs[1]): BrainFormer (6-layer encoder d=384, 6 heads x 64,
+SwiGLU 1536; window 600, patch 25 -> N=6144 tokens; 2-block perceiver with 32 queries; L1 head 128), per-GPU
+batch 32 x T=600 x 256 electrodes, bf16 compute / fp32 masters.  One step = forward + backward + (DP gradient
+all-reduce) + clip_grad_value_ + AdamW over one synthetic batch already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0.  `value` = total frames/s of the whole job (frames = B*T input time-steps).
+`roofline` is for the dominant kernel family (measured live with HIP events on the launch stream);
+`cpu_baseline` times the CPU oracle (oracle/, a port of the reference's PyTorch path) on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+MFMA_PEAK_BF16 = 2.5e15          # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+FLOP_PER_FRAME = 1.8173e9        # cfg2 fwd+bwd algorithmic FLOPs per input frame (visible attention only)
+
+
+def cfg2_model(dtype="bf16"):
+    import frankenstein_amd as fa
+    from frankenstein_amd.models import brainformer as bf
+    fa.set_compute_dtype(dtype)
+    enc = bf.MAEConfig(window_size=600, n_electrodes=256, patch_size=25, dim=384, n_layers=6, head_dim=64,
+                       hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=384, n_layers=2, head_dim=64,
+                    hidden_dim=768, n_heads=6, n_kv_heads=6)
+    return bf.BrainFormer(cfg), cfg
+
+
+def init_weights(model, seed=42):
+    """random-init weights of the architecture (no checkpoints exist offline): N(0, 1/sqrt(fan_in)) etc."""
+    from frankenstein_amd import synth
+    sd = model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if v is not None}
+    st = synth.make_state(shapes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=False)
+
+
+def attn_flops(B, H, Nq, Nk, D, C, bwd):
+    vis = 0
+    for q in range(0, Nq, C):                      # block-causal: queries of block b see (b+1)*C keys
+        vis += min(C, Nq - q) * min(Nk, (q // C + 1) * C)
+    return (10 if bwd else 4) * B * H * vis * D
+
+
+def cpu_baseline(steps=2):
+    """Oracle (port of the reference CPU path) fwd+bwd+clip+AdamW at cfg2, B=1, fp32, all host threads."""
+    from oracle import ref_models as R
+    from oracle import ref_train as RT
+    from tests import cases as C
+    cfg, x, tgt = C.cfg2(1)
+    sd = C.state(R.brainformer_shapes(cfg, "to_motion"))
+    state, cur = {}, sd
+    loss_fn = lambda s: R.brainformer_l1(s, x, tgt, cfg)[0]
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        _, _, cur = RT.train_step(loss_fn, cur, state, i + 1, 1e-3)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(600 / best, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"cfg2 brainformer-small at B=1 (600 frames/step), fp32, 1 warm-up + best of {steps} steps, "
+                      f"fwd+bwd+clip+AdamW, {best:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from frankenstein_amd import kernels as K
+    from frankenstein_amd.utils import train_utils as tu
+    model, cfg = cfg2_model(args.dtype)
+    init_weights(model)
+    model.to(dev)
+    tcfg = tu.TrainConfig(batch_size=args.batch * world, mixed_precision=(args.dtype == "bf16"), use_scheduler=False,
+                          learning_rate=1e-4)
+    opt = tu.FusedAdamW(model, lr=tcfg.learning_rate, weight_decay=tcfg.weight_decay, grad_clip=tcfg.grad_clip)
+    sched = tu.init_lr_scheduler(tcfg)
+
+    B, T, Cn = args.batch, 600, 256
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pool = [(torch.randn(B, T, Cn, device=dev, generator=g), torch.randn(B, 32, 128, device=dev, generator=g), None)
+            for _ in range(2)]                      # synthetic batches resident in HBM
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        tu.train_step(model, pool[step % 2], opt, step, tcfg, sched)
+        step += 1
+    sync()
+    if not args.no_timers:
+        K.TIMERS = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tu.train_step(model, pool[step % 2], opt, step, tcfg, sched)
+        step += 1
+    sync()
+    dt = time.perf_counter() - t0
+    timers, K.TIMERS = K.TIMERS, None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    assert torch.isfinite(loss).item(), "loss diverged"
+
+    if rank == 0:
+        frames = B * T * world * args.steps
+        value = frames / dt
+        fams = {}
+        for name, evs in (timers or {}).items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            fams[name] = (sum(ms), len(ms))
+        roof = None
+        enc = {n: v for n, v in fams.items() if n.startswith("attn_") and ":%dx6x6144x6144x64" % B in n}
+        detail = {}
+        for n, (tot, cnt) in sorted(fams.items(), key=lambda kv: -kv[1][0])[:8]:
+            detail[n] = {"ms_total_per_step": round(tot / args.steps, 3), "launches_per_step": cnt // args.steps}
+        if enc:
+            name, (tot, cnt) = max(enc.items(), key=lambda kv: kv[1][0])
+            bwd = name.startswith("attn_bwd")
+            fl = attn_flops(B, 6, 6144, 6144, 64, 256, bwd)
+            avg_s = tot / cnt / 1e3
+            roof = {"kernel": "fk_attn_bwd (delta + dK/dV + dQ kernels)" if bwd else "fk_attn_fwd",
+                    "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12,
+                    "unit": "TFLOP/s", "frac": round(fl / avg_s / MFMA_PEAK_BF16, 4), "traffic": None,
+                    "flops_per_launch": fl, "avg_launch_ms": round(avg_s * 1e3, 3)}
+        out = {
+            "metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "brainformer-small (6L d=384 6x64 heads, N=6144 tokens) + 2-block perceiver, L1 head; "
+                                   "fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world, "frames_T": T,
+                       "electrodes": Cn, "parallelism": f"dp{world}", "weights": "random-init (seed 42)"},
+            "roofline": roof,
+            "step_roofline": {"bound": "mfma", "achieved": round(value / world * FLOP_PER_FRAME / 1e12, 2),
+                              "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                              "frac": round(value / world * FLOP_PER_FRAME / MFMA_PEAK_BF16, 4),
+                              "note": "whole step per GPU: frames/s x 1.8173 GFLOP/frame (SURVEY §8d)"},
+            "kernel_families": detail,
+            "loss": round(float(loss), 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,27 @@ from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_NONE, NO
 Tensor = torch.Tensor
 
 
+# optional live instrumentation (bench.py): name -> list of (start_event, end_event) on the launch stream
+TIMERS = None
+
+
+class _timed:
+    __slots__ = ("name", "ev")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+
+    def __exit__(self, *a):
+        if TIMERS is not None:
+            self.ev[1].record()
+            TIMERS.setdefault(self.name, []).append(self.ev)
+
+
 def fk_dtype(t) -> int:
     dt = t if isinstance(t, torch.dtype) else t.dtype
     if dt == torch.bfloat16:
@@ -64,8 +85,9 @@ def gemm_nt(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
     if residual is not None:
         assert residual.dtype == a.dtype and residual.dim() == 2 and residual.stride(1) == 1 and residual.shape[1] == N
         ldr = residual.stride(0)
-    call("fk_gemm_nt", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
-         _ptr(bias), _ptr(residual), ldr, res_rows, fk_dtype(a), fk_dtype(odt), _stream())
+    with _timed(f"gemm_nt:{M}x{N}x{K}"):
+        call("fk_gemm_nt", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+             _ptr(bias), _ptr(residual), ldr, res_rows, fk_dtype(a), fk_dtype(odt), _stream())
     return out
 
 
@@ -80,8 +102,9 @@ def gemm_tn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool
         out = torch.empty((N1, N2), dtype=torch.float32, device=a.device)
     assert out.shape == (N1, N2) and out.dtype == torch.float32 and out.stride(1) == 1
     ws, nb = _ws(lib().fk_gemm_tn_workspace_bytes(M, N1, N2, fk_dtype(a)), a.device)
-    call("fk_gemm_tn", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N1, N2,
-         int(accumulate), fk_dtype(a), _ptr(ws), nb, _stream())
+    with _timed(f"gemm_tn:{M}x{N1}x{N2}"):
+        call("fk_gemm_tn", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N1, N2,
+             int(accumulate), fk_dtype(a), _ptr(ws), nb, _stream())
     return out
 
 
@@ -130,8 +153,9 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optio
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
     (qb, qr), (kb, kr), (vb, vr), (ob, orr) = _bnhd(q), _bnhd(k), _bnhd(v), _bnhd(out)
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
-    call("fk_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
-         qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, sc, fk_dtype(q), _stream())
+    with _timed(f"attn_fwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
+      call("fk_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
+           qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, sc, fk_dtype(q), _stream())
     return out, lse
 
 
@@ -145,9 +169,10 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     assert do.dtype == q.dtype and dq.dtype == q.dtype
     delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
-    call("fk_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
-         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
-         mask.kind, mask.c, mask.q_off, mask.k_off, sc, fk_dtype(q), _stream())
+    with _timed(f"attn_bwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
+      call("fk_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
+           mask.kind, mask.c, mask.q_off, mask.k_off, sc, fk_dtype(q), _stream())
 
 
 # ------------------------------------------------------------------------------------------- norms
