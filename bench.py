@@ -58,8 +58,21 @@ def attn_flops(B, H, Nq, Nk, D, C, bwd):
     return (10 if bwd else 4) * B * H * vis * D
 
 
+def host_cores() -> int:
+    """CPU share of this process: cgroup quota if any (the GPU box gives 16 of 256 logical CPUs), else affinity."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(steps=2):
     """Oracle (port of the reference CPU path) fwd+bwd+clip+AdamW at cfg2, B=1, fp32, all host threads."""
+    torch.set_num_threads(host_cores())
     from oracle import ref_models as R
     from oracle import ref_train as RT
     from tests import cases as C
