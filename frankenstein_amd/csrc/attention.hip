@@ -96,6 +96,46 @@ template <> FK_DEV void frag_tr<float>(Frag<float>& f, const char* img, int stri
     f.v[e] = reinterpret_cast<const float*>(img + (rb + acc_row_of_slot(s, h, e)) * stride)[c];
 }
 
+// ---- dual-use LDS image (row reads AND transposed reads of the same tile) ----------------------------
+// bf16, D = 64 (128-byte rows, the benchmark shape): no padding, 16-byte chunk c of row r lives at chunk
+// c ^ f(r >> 1) with f(g) = g ^ ((g & 1) << 2).  ds_read_b128 row reads (16 rows distinct mod 16, one chunk) and
+// ds_read_b64_tr_b16 reads (4 consecutive rows x 4 consecutive chunks per 32-lane half) are both conflict free.
+// Other shapes keep the padded rows of AT::RSTRIDE (row reads conflict free, transposed reads 2-way).
+template <typename T, int D> struct Img {
+  static constexpr bool SWZ = (sizeof(T) == 2 && D == 64);
+  static constexpr int STRIDE = SWZ ? 128 : AT<T, D>::RSTRIDE;
+  FK_DEV static int off(int row, int bytecol) {
+    if constexpr (SWZ) {
+      const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+      return row * 128 + ((((bytecol >> 4) ^ f) << 4) | (bytecol & 15));
+    } else {
+      return row * STRIDE + bytecol;
+    }
+  }
+};
+template <typename T, int D> FK_DEV void img_row(Frag<T>& f, const char* img, int row, int s, int h) {
+  if constexpr (sizeof(T) == 2) {
+    f.v = *reinterpret_cast<const bf16x8*>(img + Img<T, D>::off(row, (16 * s + 8 * h) * 2));
+  } else {
+    frag_load_contig<T>(f, reinterpret_cast<const T*>(img + Img<T, D>::off(row, (16 * s + 8 * h) * 4)));
+  }
+}
+template <typename T, int D> FK_DEV void img_tr(Frag<T>& f, const char* img, int rb, int s, int cb, int lane) {
+  if constexpr (sizeof(T) == 2) {
+    const int g = lane >> 4, i = lane & 15, h = g >> 1;
+    const int col = cb + 16 * (g & 1) + 4 * (i & 3);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = rb + 16 * s + 8 * t + 4 * h + (i >> 2);
+      bf16x4 v = lds_read_tr4(reinterpret_cast<const bf16_t*>(img + Img<T, D>::off(row, col * 2)));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f.v[4 * t + e] = v[e];
+    }
+  } else {
+    frag_tr<T>(f, img, Img<T, D>::STRIDE, rb, s, cb, lane);
+  }
+}
+
 // ---- global -> register -> LDS staging of a [ROWS][D] head tile -----------------------------------
 template <typename T, int D, int ROWS> struct Stager {
   using C = AT<T, D>;
@@ -116,6 +156,13 @@ template <typename T, int D, int ROWS> struct Stager {
     for (int i = 0; i < NCH; ++i) {
       const int id = tid + NT * i, row = id / C::CPR, ch = id % C::CPR;
       if (id < TOTAL) *reinterpret_cast<u32x4*>(img + row * stride + ch * 16) = r[i];
+    }
+  }
+  FK_DEV void store_img(char* img, int tid) const {   // dual-use layout (Img<T, D>)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + NT * i, row = id / C::CPR, ch = id % C::CPR;
+      if (id < TOTAL) *reinterpret_cast<u32x4*>(img + Img<T, D>::off(row, ch * 16)) = r[i];
     }
   }
 };
@@ -162,7 +209,11 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
   auto kimg = [&](int i) -> char* { return smem + i * KIMG; };
   auto vimg = [&](int i) -> char* { return smem + 2 * KIMG + i * VIMG; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * BQ;
+  // 1-D grid, XCD-aware: each XCD walks whole (batch, head) pairs (their K/V stay in its L2), heaviest
+  // (latest) query block first.
+  const int nqb = (p.Nq + BQ - 1) / BQ;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nqb), b = bh / p.H, hd = bh % p.H, q0 = (nqb - 1 - (int)(L % nqb)) * BQ;
   const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
   const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
   const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
@@ -238,10 +289,19 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[u][r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m, tmax);
-    const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m - m_new) * c);
-    const float mc = (m_new == -INFINITY) ? 0.0f : m_new * c;
-    m = m_new;
+    // exact deferred rescale: when no row's running max grows in this tile (the common case after the first
+    // tiles) alpha == 1 for every lane and the O / l rescale is skipped entirely (wave-uniform branch).
+    if (__builtin_amdgcn_ballot_w64(tmax > m) != 0) {
+      const float m_new = fmaxf(m, tmax);
+      const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m - m_new) * c);
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float mc = (m == -INFINITY) ? 0.0f : m * c;
     float rs = 0.0f;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -251,11 +311,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
         sc[u][r] = pv;
         rs += pv;
       }
-    l = l * alpha + rs;
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    l += rs;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -315,11 +371,13 @@ template <typename T, int D>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   using C = AT<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int IMG = BKV * C::RSTRIDE;
+  constexpr int IMG = BKV * C::RSTRIDE;   // (Img stride <= RSTRIDE)
   auto kimg = [&](int i) -> char* { return smem + i * IMG; };
   auto vimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * BQ;
+  const int nqb = (p.Nq + BQ - 1) / BQ;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nqb), b = bh / p.H, hd = bh % p.H, q0 = (nqb - 1 - (int)(L % nqb)) * BQ;
   const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
   const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
   const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
@@ -357,7 +415,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   if (ntiles > 0) {
     sk.load(Kp, p.k_rs, 0, p.Nk, tid);
     sv.load(Vp, p.v_rs, 0, p.Nk, tid);
-    sk.store(kimg(0), C::RSTRIDE, tid);
+    sk.store_img(kimg(0), tid);
     sv.store(vimg(0), C::RSTRIDE, tid);
   }
   __syncthreads();
@@ -383,7 +441,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
       for (int s = 0; s < C::KSTEPS; ++s) {
         Frag<T> kf, vf;
-        frag_row<T>(kf, kt, C::RSTRIDE, 32 * u + li, s, lh);
+        img_row<T, D>(kf, kt, 32 * u + li, s, lh);
         frag_row<T>(vf, vt, C::RSTRIDE, 32 * u + li, s, lh);
         mma32<T>(sc, kf, qf[s]);
         mma32<T>(dp, vf, gf[s]);
@@ -405,13 +463,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
           Frag<T> ktf;
-          frag_tr<T>(ktf, kt, C::RSTRIDE, 32 * u, s, 32 * dt, lane);
+          img_tr<T, D>(ktf, kt, 32 * u, s, 32 * dt, lane);
           mma32<T>(dq[dt], ktf, df);
         }
       }
     }
     if (t + 1 < ntiles) {
-      sk.store(kimg((t + 1) & 1), C::RSTRIDE, tid);
+      sk.store_img(kimg((t + 1) & 1), tid);
       sv.store(vimg((t + 1) & 1), C::RSTRIDE, tid);
     }
     __syncthreads();
@@ -423,7 +481,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
 // ================================================================================================= dK, dV
 // workgroup = 128 keys (wave = 32 keys, key on the lane); sweeps query tiles of 64 rows.
 template <typename T, int D>
-__global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   using C = AT<T, D>;
   constexpr int TQ = 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -432,7 +490,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs p) {
   auto gimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
   float* stats = reinterpret_cast<float*>(smem + 4 * IMG);   // [2 buffers][2 (lse2, delta)][TQ]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y, k0 = blockIdx.x * 128;
+  const int nkb = (p.Nk + 127) / 128;   // XCD-aware 1-D grid; key block 0 (seen by every query) first
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nkb), b = bh / p.H, hd = bh % p.H, k0 = (int)(L % nkb) * 128;
   const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
   const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
   const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
@@ -482,8 +542,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs p) {
     sq.load(Qp, p.q_rs, qs, p.Nq, tid);
     sg.load(Gp, p.o_rs, qs, p.Nq, tid);
     load_stats(qs);
-    sq.store(qimg(0), C::RSTRIDE, tid);
-    sg.store(gimg(0), C::RSTRIDE, tid);
+    sq.store_img(qimg(0), tid);
+    sg.store_img(gimg(0), tid);
     store_stats(0);
   }
   __syncthreads();
@@ -513,8 +573,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #pragma unroll
       for (int s = 0; s < C::KSTEPS; ++s) {
         Frag<T> qf, gf;
-        frag_row<T>(qf, qt, C::RSTRIDE, 32 * u + li, s, lh);
-        frag_row<T>(gf, gt, C::RSTRIDE, 32 * u + li, s, lh);
+        img_row<T, D>(qf, qt, 32 * u + li, s, lh);
+        img_row<T, D>(gf, gt, 32 * u + li, s, lh);
         mma32<T>(sc, qf, kf[s]);   // S[q][key]
         mma32<T>(dp, gf, vf[s]);   // dP[q][key]
       }
@@ -544,16 +604,16 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
           Frag<T> gtf, qtf;
-          frag_tr<T>(gtf, gt, C::RSTRIDE, 32 * u, s, 32 * dt, lane);
-          frag_tr<T>(qtf, qt, C::RSTRIDE, 32 * u, s, 32 * dt, lane);
+          img_tr<T, D>(gtf, gt, 32 * u, s, 32 * dt, lane);
+          img_tr<T, D>(qtf, qt, 32 * u, s, 32 * dt, lane);
           mma32<T>(dv[dt], gtf, pf);   // dV^T[d][key] += dO^T P
           mma32<T>(dk[dt], qtf, df);   // dK^T[d][key] += Q^T dS
         }
       }
     }
     if (t + 1 < ntiles) {
-      sq.store(qimg((t + 1) & 1), C::RSTRIDE, tid);
-      sg.store(gimg((t + 1) & 1), C::RSTRIDE, tid);
+      sq.store_img(qimg((t + 1) & 1), tid);
+      sg.store_img(gimg((t + 1) & 1), tid);
       store_stats((t + 1) & 1);
     }
     __syncthreads();
@@ -574,7 +634,7 @@ template <typename K> void allow_lds(K kernel, size_t bytes) {
 }
 
 template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
-  dim3 grid((a.Nq + BQ - 1) / BQ, a.H, a.B);
+  dim3 grid((unsigned)(((a.Nq + BQ - 1) / BQ) * a.H * a.B));
   const size_t lds = fwd_lds<T, D>();
   allow_lds(attn_fwd_kernel<T, D>, lds);
   hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(NT), lds, s, a);
@@ -583,12 +643,12 @@ template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
 template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.B * a.H * a.Nq;
   hipLaunchKernelGGL((attn_delta_kernel<T, D>), dim3((unsigned)fk_cdiv(total, 256)), dim3(256), 0, s, a);
-  dim3 gk((a.Nk + 127) / 128, a.H, a.B);
+  dim3 gk((unsigned)(((a.Nk + 127) / 128) * a.H * a.B));
   const size_t lds_kv = dkdv_lds<T, D>(), lds_q = dq_lds<T, D>();
   allow_lds(attn_bwd_dkdv_kernel<T, D>, lds_kv);
   allow_lds(attn_bwd_dq_kernel<T, D>, lds_q);
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D>), gk, dim3(NT), lds_kv, s, a);
-  dim3 gq((a.Nq + BQ - 1) / BQ, a.H, a.B);
+  dim3 gq((unsigned)(((a.Nq + BQ - 1) / BQ) * a.H * a.B));
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), gq, dim3(NT), lds_q, s, a);
   return 0;
 }
@@ -598,7 +658,7 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
   FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "%s: bad dtype %d", name, dtype);
   FK_CHECK_ARG(D == 8 || D == 16 || D == 32 || D == 64 || (D == 128 && dtype == FK_BF16),
                "%s: head_dim %lld unsupported (8/16/32/64, 128 for bf16)", name, (long long)D);
-  FK_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B < 65536 && H < 65536 && Nq < (1LL << 30) && Nk < (1LL << 30),
+  FK_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B < 65536 && H < 65536 && Nq < (1LL << 30) && Nk < (1LL << 30) && B * H * ((Nq + 127) / 128) < (1LL << 31) && B * H * ((Nk + 127) / 128) < (1LL << 31),
                "%s: bad shape B=%lld H=%lld Nq=%lld Nk=%lld", name, (long long)B, (long long)H, (long long)Nq, (long long)Nk);
   FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL,
                "%s: mask kind %d not supported", name, mask_kind);
