@@ -46,7 +46,7 @@ struct NtArgs {
   const void* A; const void* B; void* C;
   const void* bias; const void* res;
   int64_t lda, ldb, ldc, ldr, res_rows;
-  int M, N, K;
+  int M, N, K, vec_epi;
 };
 
 template <typename T, typename TO>
@@ -108,32 +108,86 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);   // C^T tile: rows n, cols m
     }
     if (kt + 1 < nk) lstore((kt + 1) & 1);
     __syncthreads();
   }
 
-  // epilogue: + bias[n] + residual[m % res_rows][n], cast, store (lane = column, registers = rows)
   const T* bias = (const T*)p.bias;
   const T* res = (const T*)p.res;
   TO* C = (TO*)p.C;
+  if (p.vec_epi) {
+    // Vector epilogue: accumulators are C^T tiles (lane = output row m, registers = 4 consecutive n), staged as
+    // fp32 through this wave's 16 KiB slice of the (now idle) LDS tile buffers, then swept row-wise so every
+    // global access is a full 16-byte-per-lane coalesced row segment; bias / residual added in fp32, one rounding.
+    // staged rows are 256 B (64 fp32), 16-byte chunk c of row r stored at chunk c ^ (r & 15): conflict-free for the
+    // column-of-rows b128 writes and the row-sweep b128 reads; 4 waves x 16 KiB = the 64 KiB already allocated.
+    auto eoff = [](int row, int colf) { return row * 256 + ((((colf >> 2) ^ (row & 15)) << 4) | ((colf & 3) << 2)); };
+    __syncthreads();                                // all waves finished reading the operand tiles
+    char* stg = smem + wave * (64 * 256);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + li;
-    if (n >= p.N) continue;
-    const float bv = bias ? to_f32<T>(bias[n]) : 0.0f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + acc_row(r, lh);
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bv;
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(stg + eoff(i * 32 + li, j * 32 + 8 * g + 4 * lh)) = v;
+        }
+    const int col = (lane & 7) * 8, nb = n0 + wn * 64 + col;
+    const bool col_ok = nb < p.N;                   // N % 8 == 0 on this path
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (bias && col_ok) ? to_f32<T>(bias[nb + e]) : 0.0f;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int row = ps * 8 + (lane >> 3), m = m0 + wm * 64 + row;
+      f32x4 a = *reinterpret_cast<const f32x4*>(stg + eoff(row, col));
+      f32x4 b = *reinterpret_cast<const f32x4*>(stg + eoff(row, col + 4));
+      if (m < p.M && col_ok) {
+        float v[8] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3], b[0] + bv[4], b[1] + bv[5], b[2] + bv[6], b[3] + bv[7]};
         if (res) {
           const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
-          v += to_f32<T>(res[rr * p.ldr + n]);
+          const T* rp = res + rr * p.ldr + nb;
+          if constexpr (sizeof(T) == 2) {
+            bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+          } else {
+            f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
         }
+        TO* cp = C + (int64_t)m * p.ldc + nb;
+        if constexpr (sizeof(TO) == 2) {
+          bf16x8 o8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(cp) = o8;
+        } else {
+          *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+      }
+    }
+    return;
+  }
+  // scalar epilogue (any N / ldc): lane = output row m, registers = columns n
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + li;
+    if (m >= p.M) continue;
+    const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + j * 32 + acc_row(r, lh);
+        if (n >= p.N) continue;
+        float v = acc[i][j][r] + (bias ? to_f32<T>(bias[n]) : 0.0f);
+        if (res) v += to_f32<T>(res[rr * p.ldr + n]);
         C[(int64_t)m * p.ldc + n] = from_f32<TO>(v);
       }
     }
@@ -330,7 +384,10 @@ int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   FK_CHECK_ARG(K % vec == 0 && lda % vec == 0 && ldb % vec == 0, "fk_gemm_nt: K/lda/ldb must be multiples of %d", vec);
   FK_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "fk_gemm_nt: A/B must be 16-byte aligned");
   FK_CHECK_ARG(A && B && C, "fk_gemm_nt: null pointer");
-  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K};
+  const int ovec = 8;   // epilogue handles 8 columns per lane
+  const bool vec_epi = (N % ovec == 0) && (ldc % ovec == 0) && (((uintptr_t)C & 15) == 0) &&
+                       (!residual || (ldr % ovec == 0 && ((uintptr_t)residual & 15) == 0));
+  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K, vec_epi ? 1 : 0};
   const int64_t nwg = fk_cdiv(M, BM) * fk_cdiv(N, BN);
   dim3 grid((unsigned)nwg), block(NTHREADS);
   const size_t sh = 4 * TILE_BYTES;

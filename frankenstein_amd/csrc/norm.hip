@@ -123,6 +123,95 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const T* dy, const T* 
   }
 }
 
+// Fused backward: dx (+ residual-branch gradient) AND this block's partial dgamma/dbeta in one sweep; each row is read
+// once into registers (lane owns columns lane*N + it*64*N), column partials live in registers across the block's rows
+// and are combined across the 4 waves through LDS.  part layout: [gridDim.x][2][dim].
+template <typename T, int MAXIT>
+__global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                              const float* rstd, const T* dres, T* dx, float* part,
+                                                              int64_t rows, int dim, int kind) {
+  constexpr int N = VecIO<T>::N;
+  extern __shared__ float red[];   // [4 waves][2][dim]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[MAXIT][N], ab[MAXIT][N], gm[MAXIT][N];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int c = lane * N + it * 64 * N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { ag[it][i] = 0.0f; ab[it][i] = 0.0f; gm[it][i] = (c + i < dim) ? gamma[c + i] : 0.0f; }
+  }
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += wstride) {
+    const float mu = (kind == FK_NORM_LAYER) ? mean[row] : 0.0f, rs = rstd[row];
+    float xv[MAXIT][N], gv[MAXIT][N];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int c = lane * N + it * 64 * N;
+      if (c < dim) {
+        VecIO<T>::load(x + row * dim + c, xv[it]);
+        VecIO<T>::load(dy + row * dim + c, gv[it]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          xv[it][i] = (xv[it][i] - mu) * rs;             // xhat
+          const float dg = gv[it][i] * gm[it][i];
+          s1 += dg;
+          s2 += dg * xv[it][i];
+        }
+      }
+    }
+    const float c1 = (kind == FK_NORM_LAYER) ? wave_sum(s1) / dim : 0.0f;
+    const float c2 = wave_sum(s2) / dim;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int c = lane * N + it * 64 * N;
+      if (c < dim) {
+        float o[N], rv[N];
+        if (dres) VecIO<T>::load(dres + row * dim + c, rv);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          o[i] = rs * (gv[it][i] * gm[it][i] - c1 - xv[it][i] * c2) + (dres ? rv[i] : 0.0f);
+          ag[it][i] += gv[it][i] * xv[it][i];
+          ab[it][i] += gv[it][i];
+        }
+        VecIO<T>::store(dx + row * dim + c, o);
+      }
+    }
+  }
+  if (part == nullptr) return;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int c = lane * N + it * 64 * N;
+    if (c < dim) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        red[(wave * 2 + 0) * dim + c + i] = ag[it][i];
+        red[(wave * 2 + 1) * dim + c + i] = ab[it][i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * dim; i += blockDim.x)
+    part[(int64_t)blockIdx.x * 2 * dim + i] = red[i] + red[2 * dim + i] + red[4 * dim + i] + red[6 * dim + i];
+}
+// out[which][c] = sum_k part[k][which][c]; block = 64 columns x 4 slices
+__global__ __launch_bounds__(256) void norm_bwd_fused_final(const float* part, float* dgamma, float* dbeta, int dim, int nblk, int accumulate) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, which = blockIdx.y;
+  float s = 0.0f;
+  if (c < dim)
+    for (int k = sl; k < nblk; k += 4) s += part[((int64_t)k * 2 + which) * dim + c];
+  sh[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < dim) {
+    float* out = which == 0 ? dgamma : dbeta;
+    if (out) {
+      const float t = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+      out[c] = accumulate ? out[c] + t : t;
+    }
+  }
+}
+
 // partial[chunk][0][c] = sum_r dy*xhat, partial[chunk][1][c] = sum_r dy  over the chunk's rows
 template <typename T>
 __global__ void norm_bwd_param_partial(const T* dy, const T* x, const float* mean, const float* rstd, float* part,
@@ -182,7 +271,12 @@ int fk_norm_fwd(const void* x, const float* gamma, const float* beta, void* y, f
   return FK_OK;
 }
 
-size_t fk_norm_bwd_workspace_bytes(int64_t rows, int64_t dim) { return (size_t)nchunks(rows) * 2 * dim * sizeof(float); }
+size_t fk_norm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
+  int64_t nbf = fk_cdiv(rows, 4);
+  if (nbf > 1024) nbf = 1024;
+  const int64_t n = nbf > nchunks(rows) ? nbf : nchunks(rows);
+  return (size_t)n * 2 * dim * sizeof(float);
+}
 
 int fk_norm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
                 void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t dim, int kind, int accumulate, int dtype,
@@ -193,6 +287,29 @@ int fk_norm_bwd(const void* dy, const void* x, const float* gamma, const float* 
   FK_CHECK_ARG(rows > 0 && dim > 0 && dim % vec == 0, "fk_norm_bwd: dim %lld must be a multiple of %d", (long long)dim, vec);
   FK_CHECK_ARG(dy && x && gamma && rstd && dx, "fk_norm_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  const int lanes_cols = 64 * vec;
+  if (dim <= 4 * lanes_cols && (size_t)8 * dim * sizeof(float) <= 65536) {
+    // fused sweep: dx + per-block dgamma/dbeta partials
+    const bool want = dgamma || dbeta;
+    int64_t nbf = fk_cdiv(rows, 4);
+    if (nbf > 1024) nbf = 1024;
+    if (want) FK_CHECK_ARG(workspace && workspace_bytes >= (size_t)nbf * 2 * dim * sizeof(float), "fk_norm_bwd: workspace too small");
+    float* part = want ? (float*)workspace : nullptr;
+    const size_t sh = (size_t)8 * dim * sizeof(float);
+    const int maxit = dim <= lanes_cols ? 1 : (dim <= 2 * lanes_cols ? 2 : 4);
+#define FK_NB_LAUNCH(TT, MI)                                                                                         \
+  hipLaunchKernelGGL((norm_bwd_fused_kernel<TT, MI>), dim3((unsigned)nbf), dim3(256), sh, s, (const TT*)dy, (const TT*)x, \
+                     gamma, mean, rstd, (const TT*)dres, (TT*)dx, part, rows, (int)dim, kind)
+    if (dtype == FK_BF16) { if (maxit == 1) FK_NB_LAUNCH(bf16_t, 1); else if (maxit == 2) FK_NB_LAUNCH(bf16_t, 2); else FK_NB_LAUNCH(bf16_t, 4); }
+    else { if (maxit == 1) FK_NB_LAUNCH(float, 1); else if (maxit == 2) FK_NB_LAUNCH(float, 2); else FK_NB_LAUNCH(float, 4); }
+#undef FK_NB_LAUNCH
+    FK_CHECK_LAUNCH("fk_norm_bwd(fused)");
+    if (want) {
+      hipLaunchKernelGGL(norm_bwd_fused_final, dim3((unsigned)fk_cdiv(dim, 64), 2), dim3(256), 0, s, (const float*)part, dgamma, dbeta, (int)dim, (int)nbf, accumulate);
+      FK_CHECK_LAUNCH("fk_norm_bwd(fused final)");
+    }
+    return FK_OK;
+  }
   int64_t nb = fk_cdiv(rows, 4);
   if (nb > 8192) nb = 8192;
   if (dtype == FK_BF16)
