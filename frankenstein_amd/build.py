@@ -12,7 +12,10 @@ CSRC = HERE / "csrc"
 LIB = HERE / "libfranken_hip.so"
 SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950 has a unified file), which removes the
+# v_accvgpr_read/write traffic between the matrix results and the softmax / epilogue VALU code.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _stale(out: Path, deps) -> bool:
