@@ -248,6 +248,10 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
   }
   __syncthreads();
 
+  // Everything loaded so far (the register-resident fragments) is complete before the loop: tells hipcc's waitcnt
+  // pass that the MFMA operands are ready, so inside the loop it waits only for LDS reads and the prefetched tile's
+  // global loads stay in flight behind the MFMAs (otherwise it re-waits vmcnt at the first MFMA of every iteration).
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   const float c = p.scale * LOG2E;
   float m = -INFINITY, l = 0.0f;
   f32x16 o[C::DT];
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   }
   __syncthreads();
 
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see attn_fwd_kernel
   const float c = p.scale * LOG2E;
   f32x16 dq[C::DT];
   zero_acc(dq);
@@ -525,17 +530,23 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
 
   Stager<T, D, TQ> sq, sg;
   float st_l = 0.0f, st_d = 0.0f;
+  bool st_ok = false;
+  // raw loads only: any arithmetic on the loaded value here would force an early vmcnt wait and serialise the
+  // prefetch of the next tile behind this tile's MFMAs (the scaling happens in store_stats, after the compute)
   auto load_stats = [&](int qb) {
     if (tid < TQ) {
       const int q = qb + tid;
-      st_l = q < p.Nq ? p.LSE[stat0 + q] * LOG2E : INFINITY;
-      st_d = q < p.Nq ? p.delta[stat0 + q] : 0.0f;
+      st_ok = q < p.Nq;
+      if (st_ok) {
+        st_l = p.LSE[stat0 + q];
+        st_d = p.delta[stat0 + q];
+      }
     }
   };
   auto store_stats = [&](int buf) {
     if (tid < TQ) {
-      stats[buf * 2 * TQ + tid] = st_l;
-      stats[buf * 2 * TQ + TQ + tid] = st_d;
+      stats[buf * 2 * TQ + tid] = st_ok ? st_l * LOG2E : INFINITY;
+      stats[buf * 2 * TQ + TQ + tid] = st_ok ? st_d : 0.0f;
     }
   };
   if (ntiles > 0) {
@@ -548,6 +559,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   }
   __syncthreads();
 
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see attn_fwd_kernel
   const float c = p.scale * LOG2E;
   f32x16 dk[C::DT], dv[C::DT];
   zero_acc(dk);
