@@ -208,7 +208,8 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
   constexpr int KIMG = BKV * C::RSTRIDE, VIMG = BKV * C::VSTRIDE;
   auto kimg = [&](int i) -> char* { return smem + i * KIMG; };
   auto vimg = [&](int i) -> char* { return smem + 2 * KIMG + i * VIMG; };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile predicates become scalar branches
   // 1-D grid, XCD-aware: each XCD walks whole (batch, head) pairs (their K/V stay in its L2), heaviest
   // (latest) query block first.
   const int nqb = (p.Nq + BQ - 1) / BQ;
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   constexpr int IMG = BKV * C::RSTRIDE;   // (Img stride <= RSTRIDE)
   auto kimg = [&](int i) -> char* { return smem + i * IMG; };
   auto vimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile predicates become scalar branches
   const int nqb = (p.Nq + BQ - 1) / BQ;
   const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = (int)(L / nqb), b = bh / p.H, hd = bh % p.H, q0 = (nqb - 1 - (int)(L % nqb)) * BQ;
@@ -451,15 +453,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
         mma32<T>(sc, kf, qf[s]);
         mma32<T>(dp, vf, gf[s]);
       }
-      const int qpos = qrow + p.q_off;
+      if (!boundary) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
-        if (boundary) {
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r] * c - lse2) * (dp[r] - dl);
+      } else {
+        const int qpos = qrow + p.q_off;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
           const int key = kb + 32 * u + acc_row(r, lh);
           if (!(key < p.Nk && visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))) pv = 0.0f;
+          sc[r] = pv * (dp[r] - dl);   // dS^T (without the softmax scale; folded into the final store)
         }
-        sc[r] = pv * (dp[r] - dl);   // dS^T (without the softmax scale; folded into the final store)
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -494,7 +499,8 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   auto qimg = [&](int i) -> char* { return smem + i * IMG; };
   auto gimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
   float* stats = reinterpret_cast<float*>(smem + 4 * IMG);   // [2 buffers][2 (lse2, delta)][TQ]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile predicates become scalar branches
   const int nkb = (p.Nk + 127) / 128;   // XCD-aware 1-D grid; key block 0 (seen by every query) first
   const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = (int)(L / nkb), b = bh / p.H, hd = bh % p.H, k0 = (int)(L % nkb) * 128;
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     const char* gt = gimg(t & 1);
     const float* stl = stats + (t & 1) * 2 * TQ;
     const float* std_ = stl + TQ;
-    const bool boundary = qb < full_vis_q;
+    const bool boundary = (qb < full_vis_q) || (k0 + wave * 32 + 31 >= p.Nk);   // wave-uniform
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f32x16 sc, dp;
@@ -590,22 +596,34 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
         mma32<T>(sc, qf, kf[s]);   // S[q][key]
         mma32<T>(dp, gf, vf[s]);   // dP[q][key]
       }
-      const int kpos = krow + p.k_off;
+      if (!boundary) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + 32 * u + 8 * g + 4 * lh);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(std_ + 32 * u + 8 * g + 4 * lh);
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + 32 * u + 8 * g + 4 * lh);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(std_ + 32 * u + 8 * g + 4 * lh);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g + j;
-          float pv = __builtin_amdgcn_exp2f(sc[r] * c - l4[j]);
-          if (boundary) {
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            const float pv = __builtin_amdgcn_exp2f(sc[r] * c - l4[j]);
+            sc[r] = pv;                       // P
+            dp[r] = pv * (dp[r] - d4[j]);     // dS (scale folded into the final store)
+          }
+        }
+      } else {
+        const int kpos = krow + p.k_off;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + 32 * u + 8 * g + 4 * lh);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(std_ + 32 * u + 8 * g + 4 * lh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            float pv = __builtin_amdgcn_exp2f(sc[r] * c - l4[j]);
             const int q = qb + 32 * u + acc_row(r, lh);
             if (!(k_ok && visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))) pv = 0.0f;
+            sc[r] = pv;
+            dp[r] = pv * (dp[r] - d4[j]);
           }
-          if (!k_ok) pv = 0.0f;
-          sc[r] = pv;                       // P
-          dp[r] = pv * (dp[r] - d4[j]);     // dS (scale folded into the final store)
         }
       }
 #pragma unroll
