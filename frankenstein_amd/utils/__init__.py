@@ -1,0 +1,2 @@
+"""Drop-in counterpart of the reference's ``utils`` package (train_utils)."""
+from . import train_utils  # noqa: F401

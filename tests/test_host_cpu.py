@@ -125,3 +125,18 @@ def test_param_arena_views_and_padding():
         assert torch.equal(p, b) and p.data_ptr() == a.flat.data_ptr() + 4 * o and p.grad.data_ptr() == a.grad.data_ptr() + 4 * o
     net(torch.ones(1, 5)).sum().backward()
     assert float(a.grad.abs().sum()) > 0          # autograd accumulated in place into the arena
+
+
+def test_reference_import_names_resolve(monkeypatch):
+    """the notebooks' `from models import brainformer` style imports, aliased onto this package."""
+    import sys
+    import frankenstein_amd
+    from frankenstein_amd import models, utils
+    for k, v in {"models": models, "models.brainformer": models.brainformer, "models.gpt2_model": models.gpt2_model,
+                 "utils": utils, "utils.train_utils": utils.train_utils}.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    from models import brainformer  # noqa: F401
+    from models.brainformer import Encoder, CrossBlock, build_complex_rope_cache, Config, MAEConfig  # noqa: F401
+    from models.gpt2_model import GPT, GPTConfig  # noqa: F401
+    from utils.train_utils import TrainConfig, run_train_model, count_parameters, simple_train_model, train_step  # noqa: F401
+    assert frankenstein_amd.compute_dtype() == torch.bfloat16
