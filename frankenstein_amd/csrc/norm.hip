@@ -84,6 +84,81 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* x, const float* 
   }
 }
 
+// Fast path: LPR lanes per row (16 -> 4 rows per wave, or 64), the row lives in registers (read once), exact two-pass
+// variance, LPR-wide shuffle reductions.  lane-in-row l owns columns l*N + it*LPR*N.
+template <int LPR> FK_DEV float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T, int LPR, int MAXIT>
+__global__ __launch_bounds__(256) void norm_fwd_fast_kernel(const T* x, const float* gamma, const float* beta, T* y,
+                                                             float* mean, float* rstd, int64_t rows, int dim, float eps, int kind) {
+  constexpr int N = VecIO<T>::N, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane % LPR, sub = lane / LPR;
+  float gm[MAXIT][N], bt[MAXIT][N];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int c = l * N + it * LPR * N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      gm[it][i] = (c + i < dim) ? gamma[c + i] : 0.0f;
+      bt[it][i] = (beta && c + i < dim) ? beta[c + i] : 0.0f;
+    }
+  }
+  const float inv = 1.0f / dim;
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * RPW; base < rows; base += stride) {   // wave-uniform trip count
+    const int64_t row = base + sub;
+    const bool ok = row < rows;
+    float v[MAXIT][N];
+    float s = 0.0f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int c = l * N + it * LPR * N;
+      if (ok && c < dim) VecIO<T>::load(x + row * dim + c, v[it]);
+      else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[it][i] = 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) s += v[it][i];
+    }
+    const float mu = kind == FK_NORM_LAYER ? row_sum<LPR>(s) * inv : 0.0f;
+    float q = 0.0f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int c = l * N + it * LPR * N;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const float d = (c + i < dim) ? v[it][i] - mu : 0.0f;
+        q += d * d;
+      }
+    }
+    const float rs = rsqrtf(row_sum<LPR>(q) * inv + eps);
+    if (ok) {
+      if (l == 0) {
+        if (mean) mean[row] = mu;
+        rstd[row] = rs;
+      }
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int c = l * N + it * LPR * N;
+        if (c < dim) {
+          float o[N];
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            float t = (v[it][i] - mu) * rs;
+            if (kind == FK_NORM_RMS && sizeof(T) == 2) t = (float)(bf16_t)t;
+            o[i] = t * gm[it][i] + bt[it][i];
+          }
+          VecIO<T>::store(y + row * dim + c, o);
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                            const float* rstd, const T* dres, T* dx, int64_t rows, int dim, int kind) {
@@ -124,48 +199,55 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const T* dy, const T* 
 }
 
 // Fused backward: dx (+ residual-branch gradient) AND this block's partial dgamma/dbeta in one sweep; each row is read
-// once into registers (lane owns columns lane*N + it*64*N), column partials live in registers across the block's rows
-// and are combined across the 4 waves through LDS.  part layout: [gridDim.x][2][dim].
-template <typename T, int MAXIT>
+// once into registers (LPR lanes per row, lane-in-row l owns columns l*N + it*LPR*N), column partials live in registers
+// across the block's rows and are combined across row groups (shuffles) and the 4 waves (LDS).
+// part layout: [gridDim.x][2][dim].
+template <typename T, int LPR, int MAXIT>
 __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                               const float* rstd, const T* dres, T* dx, float* part,
                                                               int64_t rows, int dim, int kind) {
-  constexpr int N = VecIO<T>::N;
+  constexpr int N = VecIO<T>::N, RPW = 64 / LPR;
   extern __shared__ float red[];   // [4 waves][2][dim]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane % LPR, sub = lane / LPR;
   float ag[MAXIT][N], ab[MAXIT][N], gm[MAXIT][N];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    const int c = lane * N + it * 64 * N;
+    const int c = l * N + it * LPR * N;
 #pragma unroll
     for (int i = 0; i < N; ++i) { ag[it][i] = 0.0f; ab[it][i] = 0.0f; gm[it][i] = (c + i < dim) ? gamma[c + i] : 0.0f; }
   }
-  const int64_t wstride = (int64_t)gridDim.x * 4;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += wstride) {
-    const float mu = (kind == FK_NORM_LAYER) ? mean[row] : 0.0f, rs = rstd[row];
+  const float inv = 1.0f / dim;
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * RPW; base < rows; base += stride) {
+    const int64_t row = base + sub;
+    const bool ok = row < rows;
+    const float mu = (ok && kind == FK_NORM_LAYER) ? mean[row] : 0.0f, rs = ok ? rstd[row] : 0.0f;
     float xv[MAXIT][N], gv[MAXIT][N];
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      const int c = lane * N + it * 64 * N;
-      if (c < dim) {
+      const int c = l * N + it * LPR * N;
+      if (ok && c < dim) {
         VecIO<T>::load(x + row * dim + c, xv[it]);
         VecIO<T>::load(dy + row * dim + c, gv[it]);
+      } else {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          xv[it][i] = (xv[it][i] - mu) * rs;             // xhat
-          const float dg = gv[it][i] * gm[it][i];
-          s1 += dg;
-          s2 += dg * xv[it][i];
-        }
+        for (int i = 0; i < N; ++i) { xv[it][i] = mu; gv[it][i] = 0.0f; }
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        xv[it][i] = (xv[it][i] - mu) * rs;             // xhat
+        const float dg = gv[it][i] * gm[it][i];
+        s1 += dg;
+        s2 += dg * xv[it][i];
       }
     }
-    const float c1 = (kind == FK_NORM_LAYER) ? wave_sum(s1) / dim : 0.0f;
-    const float c2 = wave_sum(s2) / dim;
+    const float c1 = (kind == FK_NORM_LAYER) ? row_sum<LPR>(s1) * inv : 0.0f;
+    const float c2 = row_sum<LPR>(s2) * inv;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      const int c = lane * N + it * 64 * N;
-      if (c < dim) {
+      const int c = l * N + it * LPR * N;
+      if (ok && c < dim) {
         float o[N], rv[N];
         if (dres) VecIO<T>::load(dres + row * dim + c, rv);
 #pragma unroll
@@ -180,13 +262,25 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const 
   }
   if (part == nullptr) return;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    const int c = lane * N + it * 64 * N;
-    if (c < dim) {
+  for (int it = 0; it < MAXIT; ++it)
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        red[(wave * 2 + 0) * dim + c + i] = ag[it][i];
-        red[(wave * 2 + 1) * dim + c + i] = ab[it][i];
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {           // combine the wave's row groups (same columns)
+        ag[it][i] += __shfl_xor(ag[it][i], o, 64);
+        ab[it][i] += __shfl_xor(ab[it][i], o, 64);
+      }
+    }
+  if (sub == 0) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int c = l * N + it * LPR * N;
+      if (c < dim) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          red[(wave * 2 + 0) * dim + c + i] = ag[it][i];
+          red[(wave * 2 + 1) * dim + c + i] = ab[it][i];
+        }
       }
     }
   }
@@ -260,20 +354,42 @@ int fk_norm_fwd(const void* x, const float* gamma, const float* beta, void* y, f
   FK_CHECK_ARG(rows > 0 && dim > 0 && dim % vec == 0 && dim < (1 << 24), "fk_norm_fwd: dim %lld must be a multiple of %d", (long long)dim, vec);
   FK_CHECK_ARG(x && y && gamma && rstd && (kind == FK_NORM_RMS || mean), "fk_norm_fwd: null pointer");
   FK_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "fk_norm_fwd: x/y must be 16-byte aligned");
-  int64_t nb = fk_cdiv(rows, 4);
-  if (nb > 8192) nb = 8192;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == FK_BF16)
-    hipLaunchKernelGGL(norm_fwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, (int)dim, eps, kind);
-  else
-    hipLaunchKernelGGL(norm_fwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, (int)dim, eps, kind);
+  const int per16 = 16 * vec, per64 = 64 * vec;
+#define FK_NF(TT, LPR, MI)                                                                                                 \
+  do {                                                                                                                     \
+    int64_t nbf = fk_cdiv(rows, 4 * (64 / LPR));                                                                           \
+    if (nbf > 4096) nbf = 4096;                                                                                            \
+    hipLaunchKernelGGL((norm_fwd_fast_kernel<TT, LPR, MI>), dim3((unsigned)nbf), dim3(256), 0, s, (const TT*)x, gamma, beta, \
+                       (TT*)y, mean, rstd, rows, (int)dim, eps, kind);                                                     \
+  } while (0)
+  bool done = true;
+  if (dtype == FK_BF16) {
+    if (dim <= per16) FK_NF(bf16_t, 16, 1); else if (dim <= 2 * per16) FK_NF(bf16_t, 16, 2); else if (dim <= 3 * per16) FK_NF(bf16_t, 16, 3);
+    else if (dim <= 4 * per16) FK_NF(bf16_t, 16, 4); else if (dim <= 2 * per64) FK_NF(bf16_t, 64, 2); else if (dim <= 4 * per64) FK_NF(bf16_t, 64, 4);
+    else done = false;
+  } else {
+    if (dim <= 2 * per16) FK_NF(float, 16, 2); else if (dim <= 4 * per16) FK_NF(float, 16, 4); else if (dim <= 6 * per16) FK_NF(float, 16, 6);
+    else if (dim <= 2 * per64) FK_NF(float, 64, 2); else if (dim <= 4 * per64) FK_NF(float, 64, 4);
+    else done = false;
+  }
+#undef FK_NF
+  if (!done) {
+    int64_t nb = fk_cdiv(rows, 4);
+    if (nb > 8192) nb = 8192;
+    if (dtype == FK_BF16)
+      hipLaunchKernelGGL(norm_fwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, (int)dim, eps, kind);
+    else
+      hipLaunchKernelGGL(norm_fwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, (int)dim, eps, kind);
+  }
   FK_CHECK_LAUNCH("fk_norm_fwd");
   return FK_OK;
 }
 
 size_t fk_norm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
-  int64_t nbf = fk_cdiv(rows, 4);
+  int64_t nbf = fk_cdiv(rows, 16);
   if (nbf > 1024) nbf = 1024;
+  if (nbf < 1) nbf = 1;
   const int64_t n = nbf > nchunks(rows) ? nbf : nchunks(rows);
   return (size_t)n * 2 * dim * sizeof(float);
 }
@@ -287,22 +403,28 @@ int fk_norm_bwd(const void* dy, const void* x, const float* gamma, const float* 
   FK_CHECK_ARG(rows > 0 && dim > 0 && dim % vec == 0, "fk_norm_bwd: dim %lld must be a multiple of %d", (long long)dim, vec);
   FK_CHECK_ARG(dy && x && gamma && rstd && dx, "fk_norm_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int lanes_cols = 64 * vec;
-  if (dim <= 4 * lanes_cols && (size_t)8 * dim * sizeof(float) <= 65536) {
+  const int per16 = 16 * vec, per64 = 64 * vec;
+  const bool fits = (dtype == FK_BF16 ? dim <= 4 * per64 : dim <= 4 * per64) && (size_t)8 * dim * sizeof(float) <= 65536;
+  if (fits) {
     // fused sweep: dx + per-block dgamma/dbeta partials
     const bool want = dgamma || dbeta;
-    int64_t nbf = fk_cdiv(rows, 4);
+    int64_t nbf = fk_cdiv(rows, 16);
     if (nbf > 1024) nbf = 1024;
+    if (nbf < 1) nbf = 1;
     if (want) FK_CHECK_ARG(workspace && workspace_bytes >= (size_t)nbf * 2 * dim * sizeof(float), "fk_norm_bwd: workspace too small");
     float* part = want ? (float*)workspace : nullptr;
     const size_t sh = (size_t)8 * dim * sizeof(float);
-    const int maxit = dim <= lanes_cols ? 1 : (dim <= 2 * lanes_cols ? 2 : 4);
-#define FK_NB_LAUNCH(TT, MI)                                                                                         \
-  hipLaunchKernelGGL((norm_bwd_fused_kernel<TT, MI>), dim3((unsigned)nbf), dim3(256), sh, s, (const TT*)dy, (const TT*)x, \
+#define FK_NB(TT, LPR, MI)                                                                                                  \
+  hipLaunchKernelGGL((norm_bwd_fused_kernel<TT, LPR, MI>), dim3((unsigned)nbf), dim3(256), sh, s, (const TT*)dy, (const TT*)x, \
                      gamma, mean, rstd, (const TT*)dres, (TT*)dx, part, rows, (int)dim, kind)
-    if (dtype == FK_BF16) { if (maxit == 1) FK_NB_LAUNCH(bf16_t, 1); else if (maxit == 2) FK_NB_LAUNCH(bf16_t, 2); else FK_NB_LAUNCH(bf16_t, 4); }
-    else { if (maxit == 1) FK_NB_LAUNCH(float, 1); else if (maxit == 2) FK_NB_LAUNCH(float, 2); else FK_NB_LAUNCH(float, 4); }
-#undef FK_NB_LAUNCH
+    if (dtype == FK_BF16) {
+      if (dim <= per16) FK_NB(bf16_t, 16, 1); else if (dim <= 2 * per16) FK_NB(bf16_t, 16, 2); else if (dim <= 3 * per16) FK_NB(bf16_t, 16, 3);
+      else if (dim <= 4 * per16) FK_NB(bf16_t, 16, 4); else if (dim <= 2 * per64) FK_NB(bf16_t, 64, 2); else FK_NB(bf16_t, 64, 4);
+    } else {
+      if (dim <= 2 * per16) FK_NB(float, 16, 2); else if (dim <= 4 * per16) FK_NB(float, 16, 4); else if (dim <= 6 * per16) FK_NB(float, 16, 6);
+      else if (dim <= 2 * per64) FK_NB(float, 64, 2); else FK_NB(float, 64, 4);
+    }
+#undef FK_NB
     FK_CHECK_LAUNCH("fk_norm_bwd(fused)");
     if (want) {
       hipLaunchKernelGGL(norm_bwd_fused_final, dim3((unsigned)fk_cdiv(dim, 64), 2), dim3(256), 0, s, (const float*)part, dgamma, dbeta, (int)dim, (int)nbf, accumulate);
