@@ -16,8 +16,6 @@
 //       16-lane group); the 64-B granule g of row r is stored at granule g ^ (r&3) so the 4 rows of a
 //       block hit different banks.  fp32 fragments use ds_read_b32 (conflict free unswizzled).
 // blockIdx is remapped XCD-aware (xcd_remap) so tiles that share an A row panel share an L2.
-#include <stdlib.h>
-
 #include "fk_common.h"
 
 namespace {
@@ -48,78 +46,16 @@ struct NtArgs {
   const void* A; const void* B; void* C;
   const void* bias; const void* res;
   int64_t lda, ldb, ldc, ldr, res_rows;
-  int M, N, K, vec_epi, dbg;
+  int M, N, K, vec_epi;
 };
 
+// Epilogue shared by the NT kernels: acc are C^T tiles (lane = output row m, registers = 4 consecutive n).
 template <typename T, typename TO>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BK = KT<T>::BK, VEC = KT<T>::VEC, STEPS = KT<T>::STEPS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int wave, int lane) {
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int ntn = (p.N + BN - 1) / BN;
-  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (int)(L / ntn) * BM, n0 = (int)(L % ntn) * BN;
-  const T* A = (const T*)p.A;
-  const T* B = (const T*)p.B;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  u32x4 ra[4], rb[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + NTHREADS * i, row = id >> 3, ch = id & 7, k = k0 + ch * VEC;
-      u32x4 z = {0u, 0u, 0u, 0u};
-      ra[i] = (m0 + row < p.M && k < p.K) ? *reinterpret_cast<const u32x4*>(A + (int64_t)(m0 + row) * p.lda + k) : z;
-      rb[i] = (n0 + row < p.N && k < p.K) ? *reinterpret_cast<const u32x4*>(B + (int64_t)(n0 + row) * p.ldb + k) : z;
-    }
-  };
-  auto lstore = [&](int buf) {
-    char* as = smem + buf * 2 * TILE_BYTES;
-    char* bs = as + TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + NTHREADS * i, row = id >> 3, ch = id & 7;
-      *reinterpret_cast<u32x4*>(as + nt_off(row, ch)) = ra[i];
-      *reinterpret_cast<u32x4*>(bs + nt_off(row, ch)) = rb[i];
-    }
-  };
-
-  const int nk = (p.dbg & 2) ? 1 : (p.K + BK - 1) / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * BK);
-    const char* as = smem + (kt & 1) * 2 * TILE_BYTES;
-    const char* bs = as + TILE_BYTES;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      Frag<T> fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) nt_frag<T>(fa[i], as, wm * 64 + i * 32 + li, s, lh);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);   // C^T tile: rows n, cols m
-    }
-    if (kt + 1 < nk) lstore((kt + 1) & 1);
-    __syncthreads();
-  }
-
   const T* bias = (const T*)p.bias;
   const T* res = (const T*)p.res;
   TO* C = (TO*)p.C;
-  if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;   // debug: skip the epilogue
   if (p.vec_epi) {
     // Vector epilogue: accumulators are C^T tiles (lane = output row m, registers = 4 consecutive n), staged as
     // fp32 through this wave's 16 KiB slice of the (now idle) LDS tile buffers, then swept row-wise so every
@@ -197,6 +133,142 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs p) {
   }
 }
 
+template <typename T, typename TO>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = KT<T>::BK, VEC = KT<T>::VEC, STEPS = KT<T>::STEPS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ntn = (p.N + BN - 1) / BN;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(L / ntn) * BM, n0 = (int)(L % ntn) * BN;
+  const T* A = (const T*)p.A;
+  const T* B = (const T*)p.B;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + NTHREADS * i, row = id >> 3, ch = id & 7, k = k0 + ch * VEC;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ra[i] = (m0 + row < p.M && k < p.K) ? *reinterpret_cast<const u32x4*>(A + (int64_t)(m0 + row) * p.lda + k) : z;
+      rb[i] = (n0 + row < p.N && k < p.K) ? *reinterpret_cast<const u32x4*>(B + (int64_t)(n0 + row) * p.ldb + k) : z;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* as = smem + buf * 2 * TILE_BYTES;
+    char* bs = as + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + NTHREADS * i, row = id >> 3, ch = id & 7;
+      *reinterpret_cast<u32x4*>(as + nt_off(row, ch)) = ra[i];
+      *reinterpret_cast<u32x4*>(bs + nt_off(row, ch)) = rb[i];
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const char* as = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* bs = as + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      Frag<T> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) nt_frag<T>(fa[i], as, wm * 64 + i * 32 + li, s, lh);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);   // C^T tile: rows n, cols m
+    }
+    if (kt + 1 < nk) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  nt_epilogue<T, TO>(p, acc, smem, m0, n0, wave, lane);
+}
+
+// bf16 fast path: operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 8 image rows per wave
+// instruction), no staging registers and no ds_write pass (the ds_write_b128 traffic was what bound the register-staged
+// loop).  The LDS destination of an LDS-DMA is lane-linear, so the XOR swizzle of the image is applied to the per-lane
+// SOURCE address (chunk c' of row r is fetched from logical chunk c' ^ ((r>>1)&7)); reads use nt_off unchanged.
+// Rows beyond M / N are clamped (their products are never stored); needs K % 64 == 0.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <typename TO>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(NtArgs p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ntn = (p.N + BN - 1) / BN;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(L / ntn) * BM, n0 = (int)(L % ntn) * BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const T* srcA[4];
+  const T* srcB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
+    srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ch * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    char* as = smem + buf * 2 * TILE_BYTES + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + TILE_BYTES + j * 1024), 16, 0, 0);
+    }
+  };
+  const int nk = p.K / 64;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * 64);
+    const char* as = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* bs = as + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Frag<T> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) nt_frag<T>(fa[i], as, wm * 64 + i * 32 + li, s, lh);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+    }
+    __syncthreads();   // drains this wave's LDS-DMA (vmcnt) and orders every wave's reads / DMA writes
+  }
+  nt_epilogue<T, TO>(p, acc, smem, m0, n0, wave, lane);
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 template <typename T> struct TNT;
 template <> struct TNT<bf16_t> { static constexpr int BKM = 64, ROWB = 256, CHUNKS = 16, STEPS = 4; };
@@ -241,9 +313,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs p) {
   constexpr int LOG_CH = (CHUNKS == 16) ? 4 : 5;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int nt2 = (p.N2 + BN - 1) / BN;
-  const int a0 = (int)(blockIdx.x / nt2) * BM, b0 = (int)(blockIdx.x % nt2) * BN;
-  const int split = blockIdx.y;
+  // 1-D grid, XCD-aware: logical id = (split, a-tile, b-tile) with b fastest, so one XCD owns whole M-splits: the dY slab
+  // shared by the b-tiles and the X chunk shared by the a-tiles are fetched into that XCD's L2 once.
+  const int nt2 = (p.N2 + BN - 1) / BN, ntiles = ((p.N1 + BM - 1) / BM) * nt2;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = (int)(L / ntiles), tile = (int)(L % ntiles);
+  const int a0 = (tile / nt2) * BM, b0 = (tile % nt2) * BN;
   const int mbeg = split * p.rows_per_split;
   const int mend = min(p.M, mbeg + p.rows_per_split);
   const T* A = (const T*)p.A;
@@ -361,6 +436,7 @@ int tn_splits(int64_t M, int64_t N1, int64_t N2, int bkm) {
   const int64_t tiles = fk_cdiv(N1, BM) * fk_cdiv(N2, BN);
   int64_t want = fk_cdiv(1024, tiles);                     // ~4 blocks per CU
   const int64_t maxs = fk_cdiv(M, (int64_t)bkm * 4);        // >= 4 k-tiles per split
+  if (want >= 8) want = (want + 7) / 8 * 8;                 // whole splits per XCD
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   return (int)want;
@@ -390,12 +466,15 @@ int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   const int ovec = 8;   // epilogue handles 8 columns per lane
   const bool vec_epi = (N % ovec == 0) && (ldc % ovec == 0) && (((uintptr_t)C & 15) == 0) &&
                        (!residual || (ldr % ovec == 0 && ((uintptr_t)residual & 15) == 0));
-  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K, vec_epi ? 1 : 0, getenv("FK_GEMM_DBG") ? atoi(getenv("FK_GEMM_DBG")) : 0};
+  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K, vec_epi ? 1 : 0};
   const int64_t nwg = fk_cdiv(M, BM) * fk_cdiv(N, BN);
   dim3 grid((unsigned)nwg), block(NTHREADS);
   const size_t sh = 4 * TILE_BYTES;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == FK_BF16 && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, sh, s, p);
+  const bool glds = dtype == FK_BF16 && (K % 64 == 0);
+  if (glds && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, block, sh, s, p);
+  else if (glds) hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, block, sh, s, p);
+  else if (dtype == FK_BF16 && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, sh, s, p);
   else if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, sh, s, p);
   else hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, sh, s, p);
   FK_CHECK_LAUNCH("fk_gemm_nt");
@@ -421,7 +500,7 @@ int fk_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
   FK_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "fk_gemm_tn: workspace too small (%zu < %zu)", workspace_bytes, need);
   int64_t rps = fk_cdiv(fk_cdiv(M, ns), bkm) * bkm;
   TnArgs p{A, B, C, (float*)workspace, lda, ldb, ldc, (int)M, (int)N1, (int)N2, (int)rps, ns, accumulate};
-  dim3 grid((unsigned)(fk_cdiv(N1, BM) * fk_cdiv(N2, BN)), (unsigned)ns), block(NTHREADS);
+  dim3 grid((unsigned)(fk_cdiv(N1, BM) * fk_cdiv(N2, BN) * ns)), block(NTHREADS);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 4 * TILE_BYTES, s, p);
   else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 4 * TILE_BYTES, s, p);
