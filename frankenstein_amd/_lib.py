@@ -21,6 +21,8 @@ SIGNATURES = {
     "fk_version": (_int, []),
     "fk_last_error": (C.c_char_p, []),
     "fk_gemm_nt": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _int, _int, _p]),
+    "fk_gemm_nt_swiglu": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
+    "fk_gemm_nt_dswiglu": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "fk_gemm_tn": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _int, _p, _sz, _p]),
     "fk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
@@ -37,6 +39,7 @@ SIGNATURES = {
     "fk_gelu_fwd": (_int, [_p, _p, _i64, _int, _p]),
     "fk_gelu_bwd": (_int, [_p, _p, _p, _i64, _int, _p]),
     "fk_cast_pack": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _int, _p]),
+    "fk_cast_pack_rows": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _i64, _i64, _i64, _int, _p]),
     "fk_cast": (_int, [_p, _int, _p, _int, _i64, _p]),
     "fk_add": (_int, [_p, _p, _p, _i64, _int, _p]),
     "fk_copy2d": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _p]),

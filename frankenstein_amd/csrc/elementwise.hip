@@ -159,17 +159,20 @@ __global__ void gelu_bwd_kernel(const T* x, const T* dy, T* dx, int64_t nvec) {
 }
 
 // ---------------------------------------------------------------------------------------------- casts / copies
+// dst row of source row j:  j' = (j / rblk) * rstride + (j % rblk) + roff   (rblk = 0: identity) — used to build the
+// interleaved [w1 x4 | w3 x4] SwiGLU weight shadows.
 template <typename T>
-__global__ void cast_pack_kernel(const float* src, int64_t lds, T* dst, int64_t ldd, int rows, int cols, int transpose) {
+__global__ void cast_pack_kernel(const float* src, int64_t lds, T* dst, int64_t ldd, int rows, int cols, int transpose,
+                                 int rblk, int rstride, int roff) {
   const int64_t total = (int64_t)rows * cols;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    if (transpose) {   // consecutive threads walk dst rows (= src columns): coalesced stores
-      const int r = (int)(i % rows), c = (int)(i / rows);
-      dst[(int64_t)c * ldd + r] = from_f32<T>(src[(int64_t)r * lds + c]);
-    } else {
-      const int r = (int)(i / cols), c = (int)(i % cols);
-      dst[(int64_t)r * ldd + c] = from_f32<T>(src[(int64_t)r * lds + c]);
-    }
+    int r, c;
+    if (transpose) { r = (int)(i % rows); c = (int)(i / rows); }   // consecutive threads walk dst rows: coalesced stores
+    else { r = (int)(i / cols); c = (int)(i % cols); }
+    const int rd = rblk > 0 ? (r / rblk) * rstride + (r % rblk) + roff : r;
+    const float v = src[(int64_t)r * lds + c];
+    if (transpose) dst[(int64_t)c * ldd + rd] = from_f32<T>(v);
+    else dst[(int64_t)rd * ldd + c] = from_f32<T>(v);
   }
 }
 template <typename TS, typename TD>
@@ -307,15 +310,20 @@ int fk_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, v
   return FK_OK;
 }
 
-int fk_cast_pack(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
-                 int dtype, void* stream) {
+int fk_cast_pack_rows(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
+                      int64_t rblk, int64_t rstride, int64_t roff, int dtype, void* stream) {
   FK_DT_CHECK("fk_cast_pack");
   FK_CHECK_ARG(src && dst && rows > 0 && cols > 0 && rows < (1LL << 31) && cols < (1LL << 31), "fk_cast_pack: bad shape");
+  FK_CHECK_ARG(rblk >= 0 && (rblk == 0 || (rstride >= rblk && roff >= 0)), "fk_cast_pack: bad row map");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == FK_BF16) hipLaunchKernelGGL(cast_pack_kernel<bf16_t>, dim3(grid_for(rows * cols, 8192)), dim3(TPB), 0, s, src, lds, (bf16_t*)dst, ldd, (int)rows, (int)cols, transpose);
-  else hipLaunchKernelGGL(cast_pack_kernel<float>, dim3(grid_for(rows * cols, 8192)), dim3(TPB), 0, s, src, lds, (float*)dst, ldd, (int)rows, (int)cols, transpose);
+  if (dtype == FK_BF16) hipLaunchKernelGGL(cast_pack_kernel<bf16_t>, dim3(grid_for(rows * cols, 8192)), dim3(TPB), 0, s, src, lds, (bf16_t*)dst, ldd, (int)rows, (int)cols, transpose, (int)rblk, (int)rstride, (int)roff);
+  else hipLaunchKernelGGL(cast_pack_kernel<float>, dim3(grid_for(rows * cols, 8192)), dim3(TPB), 0, s, src, lds, (float*)dst, ldd, (int)rows, (int)cols, transpose, (int)rblk, (int)rstride, (int)roff);
   FK_CHECK_LAUNCH("fk_cast_pack");
   return FK_OK;
+}
+int fk_cast_pack(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
+                 int dtype, void* stream) {
+  return fk_cast_pack_rows(src, lds, dst, ldd, rows, cols, transpose, 0, 0, 0, dtype, stream);
 }
 int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
   FK_CHECK_ARG((src_dtype == FK_F32 || src_dtype == FK_BF16) && (dst_dtype == FK_F32 || dst_dtype == FK_BF16), "fk_cast: bad dtype");

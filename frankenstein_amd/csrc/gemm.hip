@@ -47,6 +47,8 @@ struct NtArgs {
   const void* bias; const void* res;
   int64_t lda, ldb, ldc, ldr, res_rows;
   int M, N, K, vec_epi;
+  int mode;            // 0 plain, 1 SwiGLU forward (also writes g), 2 SwiGLU backward (acc = dg -> writes dh13)
+  void* aux; int64_t ldaux;
 };
 
 // Epilogue shared by the NT kernels: acc are C^T tiles (lane = output row m, registers = 4 consecutive n).
@@ -99,6 +101,48 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* smem, int m0
             for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
           }
         }
+        if (p.mode == 2) {
+          // SwiGLU backward fused into the down-projection dgrad: v = dg[m, nb..nb+7]; h13 / dh13 use the interleaved hidden
+          // layout (per 4 hidden units: 4 x h1 then 4 x h3), so the 8 units of this lane are 16 contiguous columns.
+          if constexpr (sizeof(TO) == sizeof(T)) {
+            const T* hp = (const T*)p.aux + (int64_t)m * p.ldaux + 2 * nb;
+            T* dp = (T*)p.C + (int64_t)m * p.ldc + 2 * nb;
+            float hv[16], ov[16];
+            if constexpr (sizeof(T) == 2) {
+              bf16x8 h0 = *reinterpret_cast<const bf16x8*>(hp), h1 = *reinterpret_cast<const bf16x8*>(hp + 8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { hv[e] = (float)h0[e]; hv[8 + e] = (float)h1[e]; }
+            } else {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(hp + 4 * q4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[4 * q4 + e] = t[e];
+              }
+            }
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float a1 = hv[8 * gq + e], a3 = hv[8 * gq + 4 + e], dg = v[4 * gq + e];
+                const float sg = 1.0f / (1.0f + __expf(-a1));
+                ov[8 * gq + e] = dg * a3 * sg * (1.0f + a1 * (1.0f - sg));
+                ov[8 * gq + 4 + e] = dg * a1 * sg;
+              }
+            if constexpr (sizeof(T) == 2) {
+              bf16x8 o0, o1;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { o0[e] = (bf16_t)ov[e]; o1[e] = (bf16_t)ov[8 + e]; }
+              *reinterpret_cast<bf16x8*>(dp) = o0;
+              *reinterpret_cast<bf16x8*>(dp + 8) = o1;
+            } else {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4)
+                *reinterpret_cast<f32x4*>(dp + 4 * q4) = f32x4{ov[4 * q4], ov[4 * q4 + 1], ov[4 * q4 + 2], ov[4 * q4 + 3]};
+            }
+          }
+          continue;
+        }
         TO* cp = C + (int64_t)m * p.ldc + nb;
         if constexpr (sizeof(TO) == 2) {
           bf16x8 o8;
@@ -108,6 +152,23 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* smem, int m0
         } else {
           *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
           *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        if (p.mode == 1) {
+          // SwiGLU forward fused into the up-projection: the 8 columns are (h1[4], h3[4]) of 4 hidden units
+          if constexpr (sizeof(TO) == sizeof(T)) {
+            T* gp = (T*)p.aux + (int64_t)m * p.ldaux + (nb >> 1);
+            float gq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gq[e] = v[e] / (1.0f + __expf(-v[e])) * v[4 + e];
+            if constexpr (sizeof(T) == 2) {
+              bf16x4 g4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) g4[e] = (bf16_t)gq[e];
+              *reinterpret_cast<bf16x4*>(gp) = g4;
+            } else {
+              *reinterpret_cast<f32x4*>(gp) = f32x4{gq[0], gq[1], gq[2], gq[3]};
+            }
+          }
         }
       }
     }
@@ -452,21 +513,24 @@ int colsum_blocks(int64_t rows) {
 
 extern "C" {
 
-int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
-               int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
-               int out_dtype, void* stream) {
-  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_gemm_nt: bad dtype %d", dtype);
-  FK_CHECK_ARG(out_dtype == dtype || out_dtype == FK_F32, "fk_gemm_nt: out_dtype must equal dtype or be f32");
+static int launch_nt(const char* name, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                     int64_t N, int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
+                     int out_dtype, int mode, void* aux, int64_t ldaux, void* stream) {
+  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "%s: bad dtype %d", name, dtype);
+  FK_CHECK_ARG(out_dtype == dtype || out_dtype == FK_F32, "%s: out_dtype must equal dtype or be f32", name);
   const int vec = dtype == FK_BF16 ? 8 : 4;
-  FK_CHECK_ARG(M > 0 && N > 0 && K > 0, "fk_gemm_nt: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
-  FK_CHECK_ARG(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "fk_gemm_nt: dims must fit int32");
-  FK_CHECK_ARG(K % vec == 0 && lda % vec == 0 && ldb % vec == 0, "fk_gemm_nt: K/lda/ldb must be multiples of %d", vec);
-  FK_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "fk_gemm_nt: A/B must be 16-byte aligned");
-  FK_CHECK_ARG(A && B && C, "fk_gemm_nt: null pointer");
+  FK_CHECK_ARG(M > 0 && N > 0 && K > 0, "%s: empty problem M=%lld N=%lld K=%lld", name, (long long)M, (long long)N, (long long)K);
+  FK_CHECK_ARG(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "%s: dims must fit int32", name);
+  FK_CHECK_ARG(K % vec == 0 && lda % vec == 0 && ldb % vec == 0, "%s: K/lda/ldb must be multiples of %d", name, vec);
+  FK_CHECK_ARG(A && B && C, "%s: null pointer", name);
+  FK_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "%s: A/B must be 16-byte aligned", name);
   const int ovec = 8;   // epilogue handles 8 columns per lane
   const bool vec_epi = (N % ovec == 0) && (ldc % ovec == 0) && (((uintptr_t)C & 15) == 0) &&
                        (!residual || (ldr % ovec == 0 && ((uintptr_t)residual & 15) == 0));
-  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K, vec_epi ? 1 : 0};
+  if (mode != 0)
+    FK_CHECK_ARG(vec_epi && out_dtype == dtype && aux && ldaux % ovec == 0 && ((uintptr_t)aux & 15) == 0,
+                 "%s: fused SwiGLU epilogue needs N %% 8 == 0 and 16-byte aligned, 8-element strided buffers", name);
+  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K, vec_epi ? 1 : 0, mode, aux, ldaux};
   const int64_t nwg = fk_cdiv(M, BM) * fk_cdiv(N, BN);
   dim3 grid((unsigned)nwg), block(NTHREADS);
   const size_t sh = 4 * TILE_BYTES;
@@ -477,8 +541,29 @@ int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   else if (dtype == FK_BF16 && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, sh, s, p);
   else if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, sh, s, p);
   else hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, sh, s, p);
-  FK_CHECK_LAUNCH("fk_gemm_nt");
+  FK_CHECK_LAUNCH(name);
   return FK_OK;
+}
+
+int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+               int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
+               int out_dtype, void* stream) {
+  return launch_nt("fk_gemm_nt", A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_rows, dtype, out_dtype, 0, nullptr, 0, stream);
+}
+
+int fk_gemm_nt_swiglu(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G,
+                      int64_t ldg, int64_t M, int64_t H, int64_t K, int dtype, void* stream) {
+  FK_CHECK_ARG(H > 0 && H % 4 == 0, "fk_gemm_nt_swiglu: hidden size must be a multiple of 4");
+  return launch_nt("fk_gemm_nt_swiglu", A, lda, W13, ldb, H13, ldh, M, 2 * H, K, nullptr, nullptr, 0, 0, dtype, dtype, 1, G, ldg, stream);
+}
+
+int fk_gemm_nt_dswiglu(const void* dY, int64_t lda, const void* W2T, int64_t ldb, const void* H13, int64_t ldh, void* dH13,
+                       int64_t lddh, int64_t M, int64_t H, int64_t K, int dtype, void* stream) {
+  FK_CHECK_ARG(H > 0 && H % 8 == 0, "fk_gemm_nt_dswiglu: hidden size must be a multiple of 8");
+  FK_CHECK_ARG(lddh % 8 == 0 && ((uintptr_t)dH13 & 15) == 0, "fk_gemm_nt_dswiglu: dH13 must be 16-byte aligned with an 8-element stride");
+  // C pointer/ld are the dh13 buffer (2H columns); the accumulator tile (dg) has H columns
+  return launch_nt("fk_gemm_nt_dswiglu", dY, lda, W2T, ldb, dH13, lddh, M, H, K, nullptr, nullptr, 0, 0, dtype, dtype, 2,
+                   const_cast<void*>(H13), ldh, stream);
 }
 
 size_t fk_gemm_tn_workspace_bytes(int64_t M, int64_t N1, int64_t N2, int dtype) {

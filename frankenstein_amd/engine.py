@@ -100,6 +100,37 @@ def shadow(params: Sequence[Tensor], transpose: bool = False, pad_k: int = 0, pa
     return out
 
 
+def shadow_swiglu(w1: Tensor, w3: Tensor, transpose: bool = False) -> Tensor:
+    """Interleaved SwiGLU up-projection shadow: per 4 hidden units, 4 rows of w1 then 4 rows of w3 ([2H, K]; transposed
+    [K, 2H]) — the layout the fused GEMM epilogues (fk_gemm_nt_swiglu / fk_gemm_nt_dswiglu) expect."""
+    dt = _COMPUTE_DTYPE
+    key = (("swiglu", w1.data_ptr(), w3.data_ptr(), tuple(w1.shape)), transpose, dt)
+    stamp = (_EPOCH, w1._version, w3._version)
+    ent = _SHADOWS.get(key)
+    if ent is None:
+        ent = _SHADOWS[key] = _Shadow()
+    if ent.stamp == stamp:
+        return ent.tensor
+    H, Kd = w1.shape
+    assert w3.shape == (H, Kd) and H % 8 == 0 and w1.dtype == torch.float32 and w1.is_contiguous() and w3.is_contiguous()
+    out = torch.empty((Kd, 2 * H) if transpose else (2 * H, Kd), dtype=dt, device=w1.device)
+    K.cast_pack_rows(w1.detach(), out, transpose, 4, 8, 0)
+    K.cast_pack_rows(w3.detach(), out, transpose, 4, 8, 4)
+    ent.stamp, ent.tensor = stamp, out
+    return out
+
+
+def _deinterleave_rows(t: Tensor, H: int):
+    """[2H, K] fp32 in the interleaved row order -> (rows of w1, rows of w3), each [H, K] contiguous."""
+    Kd = t.shape[1]
+    a = torch.empty((H, Kd), dtype=t.dtype, device=t.device)
+    b = torch.empty((H, Kd), dtype=t.dtype, device=t.device)
+    v = t.view(H // 4, 8 * Kd)
+    K.copy2d(v[:, :4 * Kd], a.view(H // 4, 4 * Kd))
+    K.copy2d(v[:, 4 * Kd:], b.view(H // 4, 4 * Kd))
+    return a, b
+
+
 def _split_rows(t: Tensor, params: Sequence[Tensor]) -> List[Tensor]:
     out, off = [], 0
     for p in params:
@@ -257,12 +288,16 @@ class MlpBranch(torch.autograd.Function):
             h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps)
         else:
             h, mean, rstd = x2, None, None
-        ups = [up_w] if gate_w is None else [up_w, gate_w]
-        a = K.gemm_nt(h, shadow(ups), bias=None if up_b is None else shadow([up_b]))
-        g = K.gelu_fwd(a) if gate_w is None else K.swiglu_fwd(a)
+        fused = gate_w is not None and up_b is None and up_w.shape[0] % 8 == 0
+        if fused:     # up-projection + SwiGLU in one kernel (interleaved hidden layout)
+            a, g = K.gemm_nt_swiglu(h, shadow_swiglu(up_w, gate_w))
+        else:
+            ups = [up_w] if gate_w is None else [up_w, gate_w]
+            a = K.gemm_nt(h, shadow(ups), bias=None if up_b is None else shadow([up_b]))
+            g = K.gelu_fwd(a) if gate_w is None else K.swiglu_fwd(a)
         y = K.gemm_nt(g, shadow([down_w]), bias=None if down_b is None else shadow([down_b]),
                       residual=x2 if residual else None)
-        ctx.spec, ctx.has_ln = spec, has_ln
+        ctx.spec, ctx.has_ln, ctx.fused = spec, has_ln, fused
         ctx.flags = (ln_b is not None, up_b is not None, gate_w is not None, down_b is not None)
         ctx.save_for_backward(x, ln_w, up_w, gate_w, down_w, h if has_ln else None, mean, rstd, a, g)
         return y.view(*shp[:-1], y.shape[-1])
@@ -279,12 +314,17 @@ class MlpBranch(torch.autograd.Function):
             h = x2
         dy2 = dy.contiguous().view(x2.shape[0], -1)
         ups = [up_w, gate_w] if gated else [up_w]
-        dg_ = K.gemm_nt(dy2, shadow([down_w], transpose=True))
         ddown = K.gemm_tn(dy2, g)
         ddb = K.colsum(dy2) if has_db else None
-        da = K.swiglu_bwd(a, dg_) if gated else K.gelu_bwd(a, dg_)
-        dh = K.gemm_nt(da, shadow(ups, transpose=True))
-        dups = _split_rows(K.gemm_tn(da, h), ups)
+        if ctx.fused:   # down-projection dgrad + SwiGLU backward in one kernel; dg is never materialised
+            da = K.gemm_nt_dswiglu(dy2, shadow([down_w], transpose=True), a)
+            dh = K.gemm_nt(da, shadow_swiglu(up_w, gate_w, transpose=True))
+            dups = _deinterleave_rows(K.gemm_tn(da, h), up_w.shape[0])
+        else:
+            dg_ = K.gemm_nt(dy2, shadow([down_w], transpose=True))
+            da = K.swiglu_bwd(a, dg_) if gated else K.gelu_bwd(a, dg_)
+            dh = K.gemm_nt(da, shadow(ups, transpose=True))
+            dups = _split_rows(K.gemm_tn(da, h), ups)
         dub = K.colsum(da) if has_ub else None
         if ctx.has_ln:
             dx, dgam, dbet = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, want_beta=has_lnb)

@@ -91,6 +91,34 @@ def gemm_nt(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
     return out
 
 
+def gemm_nt_swiglu(a: Tensor, w13: Tensor) -> Tuple[Tensor, Tensor]:
+    """(h13 [M, 2H] interleaved, g [M, H]) = fused up-projection + SwiGLU; w13 is the interleaved [2H, K] shadow."""
+    assert a.dim() == 2 and w13.dim() == 2 and a.shape[1] == w13.shape[1] and a.dtype == w13.dtype
+    assert a.stride(1) == 1 and w13.is_contiguous()
+    M, Kd = a.shape
+    H = w13.shape[0] // 2
+    h13 = torch.empty((M, 2 * H), dtype=a.dtype, device=a.device)
+    g = torch.empty((M, H), dtype=a.dtype, device=a.device)
+    with _timed(f"gemm_nt_swiglu:{M}x{2 * H}x{Kd}"):
+        call("fk_gemm_nt_swiglu", a.data_ptr(), a.stride(0), w13.data_ptr(), w13.stride(0), h13.data_ptr(), 2 * H,
+             g.data_ptr(), H, M, H, Kd, fk_dtype(a), _stream())
+    return h13, g
+
+
+def gemm_nt_dswiglu(dy: Tensor, w2t: Tensor, h13: Tensor) -> Tensor:
+    """dh13 [M, 2H] (interleaved) from dy [M, d], the transposed down-projection shadow w2t [H, d] and the saved h13."""
+    assert dy.dim() == 2 and w2t.dim() == 2 and dy.shape[1] == w2t.shape[1] and dy.dtype == w2t.dtype == h13.dtype
+    assert dy.stride(1) == 1 and w2t.is_contiguous() and h13.is_contiguous()
+    M, Kd = dy.shape
+    H = w2t.shape[0]
+    assert h13.shape == (M, 2 * H)
+    dh13 = torch.empty_like(h13)
+    with _timed(f"gemm_nt_dswiglu:{M}x{H}x{Kd}"):
+        call("fk_gemm_nt_dswiglu", dy.data_ptr(), dy.stride(0), w2t.data_ptr(), w2t.stride(0), h13.data_ptr(), 2 * H,
+             dh13.data_ptr(), 2 * H, M, H, Kd, fk_dtype(dy), _stream())
+    return dh13
+
+
 def gemm_tn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     """out[N1,N2] (fp32) (+)= a[M,N1]^T @ b[M,N2]."""
     assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.dtype == b.dtype
@@ -266,6 +294,15 @@ def cast_pack(src: Tensor, dst: Tensor, transpose: bool = False) -> Tensor:
     rows, cols = src.shape
     call("fk_cast_pack", src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), rows, cols, int(transpose),
          fk_dtype(dst), _stream())
+    return dst
+
+
+def cast_pack_rows(src: Tensor, dst: Tensor, transpose: bool, rblk: int, rstride: int, roff: int) -> Tensor:
+    """cast_pack with the row map j -> (j // rblk) * rstride + j % rblk + roff (interleaved SwiGLU weight shadows)."""
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1 and dst.dim() == 2 and dst.stride(1) == 1
+    rows, cols = src.shape
+    call("fk_cast_pack_rows", src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), rows, cols, int(transpose),
+         rblk, rstride, roff, fk_dtype(dst), _stream())
     return dst
 
 

@@ -46,6 +46,15 @@ const char* fk_last_error(void);
 int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
                int out_dtype, void* stream);
+/* SwiGLU MLP fused into the projection epilogues (models/brainformer.py:124 and its autograd).  Hidden units use the
+ * INTERLEAVED layout: for every 4 hidden units, 4 columns of h1 = w1 x followed by 4 columns of h3 = w3 x (W13 rows are
+ * packed the same way, see fk_cast_pack_rows).
+ *   fk_gemm_nt_swiglu : H13[M,2H] = A[M,K] * W13[2H,K]^T   and   G[M,H] = silu(h1) * h3        (one pass, G never re-read)
+ *   fk_gemm_nt_dswiglu: dg = dY[M,K] * W2T[H,K]^T (never stored);  dH13[M,2H] = d(silu(h1) h3)/d(h1,h3) * dg         */
+int fk_gemm_nt_swiglu(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G,
+                      int64_t ldg, int64_t M, int64_t H, int64_t K, int dtype, void* stream);
+int fk_gemm_nt_dswiglu(const void* dY, int64_t lda, const void* W2T, int64_t ldb, const void* H13, int64_t ldh, void* dH13,
+                       int64_t lddh, int64_t M, int64_t H, int64_t K, int dtype, void* stream);
 /* fk_gemm_tn: C[N1,N2] (fp32) (+)= sum_m A[m,N1] * B[m,N2]  — the weight gradient dW = dY^T X of a Linear
  *   (autograd of the call sites above).  Split over m with deterministic slab reduction.                     */
 size_t fk_gemm_tn_workspace_bytes(int64_t M, int64_t N1, int64_t N2, int dtype);
@@ -105,6 +114,9 @@ int fk_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, v
 /* ---- dtype / layout plumbing for weight shadows: dst[r*ldd + c] = src[r*lds + c] (or transposed: dst[c*ldd + r]).*/
 int fk_cast_pack(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
                  int dtype, void* stream);
+/* same with a row map: source row j lands in destination row (j / rblk) * rstride + j % rblk + roff (rblk = 0: identity). */
+int fk_cast_pack_rows(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
+                      int64_t rblk, int64_t rstride, int64_t roff, int dtype, void* stream);
 int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* y = a + b (same dtype) */
 int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);

@@ -355,3 +355,35 @@ def test_errors_are_loud(K):
         K.gemm_nt(torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16), torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16))
     with pytest.raises(FrankenHipError, match="head_dim"):
         K.attn_fwd(torch.zeros(1, 8, 1, 24, device="cuda"), torch.zeros(1, 8, 1, 24, device="cuda"), torch.zeros(1, 8, 1, 24, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_fused_swiglu_gemms(K, dtype):
+    """up-projection + SwiGLU and down-projection dgrad + SwiGLU backward fused in the GEMM epilogues (interleaved layout)."""
+    from frankenstein_amd import engine as E
+    E.set_compute_dtype(dtype)
+    try:
+        M, d, H = 300, 64, 96
+        x, w1, w3, w2 = rnd(M, d, seed=1), rnd(H, d, seed=2, scale=0.2), rnd(H, d, seed=3, scale=0.2), rnd(d, H, seed=4, scale=0.2)
+        dy = rnd(M, d, seed=5)
+        w1d, w3d, w2d = dev(w1), dev(w3), dev(w2)
+        h13, g = K.gemm_nt_swiglu(dev(x, dtype), E.shadow_swiglu(w1d, w3d))
+        xr = q(x, dtype)
+        h1, h3 = xr @ q(w1, dtype).t(), xr @ q(w3, dtype).t()
+        close(g, R.silu(h1) * h3, dtype, atol32=2e-5)
+        il = h13.float().cpu().view(M, H // 4, 2, 4)
+        close(il[:, :, 0].reshape(M, H), h1, dtype, atol32=2e-5)
+        close(il[:, :, 1].reshape(M, H), h3, dtype, atol32=2e-5)
+        # backward: dh13 from dy, w2^T and the saved (interleaved) h13
+        dh13 = K.gemm_nt_dswiglu(dev(dy, dtype), E.shadow([w2d], transpose=True), h13)
+        h1r = il[:, :, 0].reshape(M, H).clone().requires_grad_(True)
+        h3r = il[:, :, 1].reshape(M, H).clone().requires_grad_(True)
+        (R.silu(h1r) * h3r).backward(q(dy, dtype) @ q(w2, dtype))
+        dil = dh13.float().cpu().view(M, H // 4, 2, 4)
+        close(dil[:, :, 0].reshape(M, H), h1r.grad, dtype, atol32=5e-5, atol16=4e-2)
+        close(dil[:, :, 1].reshape(M, H), h3r.grad, dtype, atol32=5e-5, atol16=4e-2)
+        a, b = E._deinterleave_rows(dev(torch.arange(2 * H * 8, dtype=torch.float32).view(2 * H, 8)), H)
+        ref = torch.arange(2 * H * 8, dtype=torch.float32).view(H // 4, 2, 4, 8)
+        assert torch.equal(a.cpu(), ref[:, 0].reshape(H, 8)) and torch.equal(b.cpu(), ref[:, 1].reshape(H, 8))
+    finally:
+        E.set_compute_dtype("bf16")
