@@ -167,6 +167,25 @@ template <typename T, int D, int ROWS> struct Stager {
   }
 };
 
+// LDS-DMA (global_load_lds_dwordx4) loader for a [ROWS][64] bf16 head tile in the Img<bf16,64> layout: one wave
+// instruction fills 8 image rows (1 KiB, lane-linear), so the chunk swizzle is applied to the per-lane source address.
+// Rows past nrows are clamped to the last valid row (finite data; the mask / LSE=+inf zeroes their contribution).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+template <int ROWS>
+FK_DEV void dma_tile_bf16_d64(const bf16_t* base, int64_t rs, int row0, int nrows, char* img, int wave, int lane) {
+  constexpr int PER_WAVE = ROWS / 8 / 4;   // wave instructions per wave
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int grp = wave * PER_WAVE + j;               // 8-row group
+    const int row = grp * 8 + (lane >> 3);
+    const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+    const int ch = (lane & 7) ^ f;                     // logical chunk stored at physical chunk (lane & 7)
+    const bf16_t* src = base + (int64_t)min(row0 + row, nrows - 1) * rs + ch * 8;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(img + grp * 1024), 16, 0, 0);
+  }
+}
+
 template <int N> FK_DEV void zero_acc(f32x16 (&a)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i)
@@ -491,7 +510,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
 // ================================================================================================= dK, dV
 // workgroup = 128 keys (wave = 32 keys, key on the lane); sweeps query tiles of 64 rows.
 template <typename T, int D>
-__global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_bwd_dkdv_kernel(AttnArgs p) {
   using C = AT<T, D>;
   constexpr int TQ = 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -534,7 +553,8 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   const int full_vis_q = q_first(p, min(k0 + wave * 32 + 31, p.Nk - 1));
   const int64_t stat0 = ((int64_t)b * p.H + hd) * p.Nq;
 
-  Stager<T, D, TQ> sq, sg;
+  constexpr bool DMA = Img<T, D>::SWZ;          // bf16, D = 64: tiles arrive by LDS-DMA, no staging registers
+  Stager<T, D, DMA ? 4 : TQ> sq, sg;            // (register staging kept for the other shapes)
   float st_l = 0.0f, st_d = 0.0f;
   bool st_ok = false;
   // raw loads only: any arithmetic on the loaded value here would force an early vmcnt wait and serialise the
@@ -556,11 +576,18 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     }
   };
   if (ntiles > 0) {
-    sq.load(Qp, p.q_rs, qs, p.Nq, tid);
-    sg.load(Gp, p.o_rs, qs, p.Nq, tid);
+    if constexpr (DMA) {
+      dma_tile_bf16_d64<TQ>((const bf16_t*)Qp, p.q_rs, qs, p.Nq, qimg(0), wave, lane);
+      dma_tile_bf16_d64<TQ>((const bf16_t*)Gp, p.o_rs, qs, p.Nq, gimg(0), wave, lane);
+    } else {
+      sq.load(Qp, p.q_rs, qs, p.Nq, tid);
+      sg.load(Gp, p.o_rs, qs, p.Nq, tid);
+    }
     load_stats(qs);
-    sq.store_img(qimg(0), tid);
-    sg.store_img(gimg(0), tid);
+    if constexpr (!DMA) {
+      sq.store_img(qimg(0), tid);
+      sg.store_img(gimg(0), tid);
+    }
     store_stats(0);
   }
   __syncthreads();
@@ -574,8 +601,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   for (int t = 0; t < ntiles; ++t) {
     const int qb = qs + t * TQ;
     if (t + 1 < ntiles) {
-      sq.load(Qp, p.q_rs, qb + TQ, p.Nq, tid);
-      sg.load(Gp, p.o_rs, qb + TQ, p.Nq, tid);
+      if constexpr (DMA) {
+        dma_tile_bf16_d64<TQ>((const bf16_t*)Qp, p.q_rs, qb + TQ, p.Nq, qimg((t + 1) & 1), wave, lane);
+        dma_tile_bf16_d64<TQ>((const bf16_t*)Gp, p.o_rs, qb + TQ, p.Nq, gimg((t + 1) & 1), wave, lane);
+      } else {
+        sq.load(Qp, p.q_rs, qb + TQ, p.Nq, tid);
+        sg.load(Gp, p.o_rs, qb + TQ, p.Nq, tid);
+      }
       load_stats(qb + TQ);
     }
     const char* qt = qimg(t & 1);
@@ -583,19 +615,24 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     const float* stl = stats + (t & 1) * 2 * TQ;
     const float* std_ = stl + TQ;
     const bool boundary = (qb < full_vis_q) || (k0 + wave * 32 + 31 >= p.Nk);   // wave-uniform
+    // phase 1: S = Q K^T and dP = dO V^T for both 32-row query sub-tiles (16 MFMAs back to back)
+    f32x16 sc[2], dp[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      f32x16 sc, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+      for (int r = 0; r < 16; ++r) { sc[u][r] = 0.0f; dp[u][r] = 0.0f; }
 #pragma unroll
       for (int s = 0; s < C::KSTEPS; ++s) {
         Frag<T> qf, gf;
         img_row<T, D>(qf, qt, 32 * u + li, s, lh);
         img_row<T, D>(gf, gt, 32 * u + li, s, lh);
-        mma32<T>(sc, qf, kf[s]);   // S[q][key]
-        mma32<T>(dp, gf, vf[s]);   // dP[q][key]
+        mma32<T>(sc[u], qf, kf[s]);   // S[q][key]
+        mma32<T>(dp[u], gf, vf[s]);   // dP[q][key]
       }
+    }
+    // phase 2: P = exp2(c S - lse2), dS = P (dP - delta)   (VALU; overlaps the partner wave's MFMA phases)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
       if (!boundary) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -604,9 +641,9 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j;
-            const float pv = __builtin_amdgcn_exp2f(sc[r] * c - l4[j]);
-            sc[r] = pv;                       // P
-            dp[r] = pv * (dp[r] - d4[j]);     // dS (scale folded into the final store)
+            const float pv = __builtin_amdgcn_exp2f(sc[u][r] * c - l4[j]);
+            sc[u][r] = pv;                          // P
+            dp[u][r] = pv * (dp[u][r] - d4[j]);     // dS (scale folded into the final store)
           }
         }
       } else {
@@ -618,19 +655,23 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j;
-            float pv = __builtin_amdgcn_exp2f(sc[r] * c - l4[j]);
+            float pv = __builtin_amdgcn_exp2f(sc[u][r] * c - l4[j]);
             const int q = qb + 32 * u + acc_row(r, lh);
             if (!(k_ok && visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))) pv = 0.0f;
-            sc[r] = pv;
-            dp[r] = pv * (dp[r] - d4[j]);
+            sc[u][r] = pv;
+            dp[u][r] = pv * (dp[u][r] - d4[j]);
           }
         }
       }
+    }
+    // phase 3: dV^T += dO^T P, dK^T += Q^T dS (16 MFMAs)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         Frag<T> pf, df;
-        frag_from_acc<T>(pf, sc, s);
-        frag_from_acc<T>(df, dp, s);
+        frag_from_acc<T>(pf, sc[u], s);
+        frag_from_acc<T>(df, dp[u], s);
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
           Frag<T> gtf, qtf;
@@ -640,10 +681,11 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
           mma32<T>(dk[dt], qtf, df);   // dK^T[d][key] += Q^T dS
         }
       }
-    }
     if (t + 1 < ntiles) {
-      sq.store_img(qimg((t + 1) & 1), tid);
-      sg.store_img(gimg((t + 1) & 1), tid);
+      if constexpr (!DMA) {
+        sq.store_img(qimg((t + 1) & 1), tid);
+        sg.store_img(gimg((t + 1) & 1), tid);
+      }
       store_stats((t + 1) & 1);
     }
     __syncthreads();

@@ -278,56 +278,66 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(NtArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int ntn = (p.N + BN - 1) / BN;
-  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (int)(L / ntn) * BM, n0 = (int)(L % ntn) * BN;
+  const int ntiles = ((p.M + BM - 1) / BM) * ntn;
+  // Persistent blocks (the grid is a few blocks per CU, not one per tile: at 128x128 the workgroup dispatch rate, not
+  // the math, bounded the short-K GEMMs).  Blocks b, b+8, ... share an XCD (round-robin dispatch); XCD x owns the
+  // contiguous tile range [x*T/8, (x+1)*T/8) and its blocks walk it round-robin, so concurrently running blocks of an XCD
+  // work on neighbouring tiles (same A row panel in that XCD's L2).  Pure speed: any placement is correct.
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = (nb + 7 - xcd) >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int t_beg = xcd * q8 + min(xcd, r8), t_end = t_beg + q8 + (xcd < r8 ? 1 : 0);
 
-  f32x16 acc[2][2];
+  for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const T* srcA[4];
-  const T* srcB[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + (lane >> 3);
-    const int ch = (lane & 7) ^ ((row >> 1) & 7);
-    srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
-    srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ch * 8;
-  }
-  auto stage = [&](int buf, int k0) {
-    char* as = smem + buf * 2 * TILE_BYTES + wave * 4096;
+    const T* srcA[4];
+    const T* srcB[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + TILE_BYTES + j * 1024), 16, 0, 0);
+      const int row = (wave * 4 + j) * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
+      srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ch * 8;
     }
-  };
-  const int nk = p.K / 64;
-  stage(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * 64);
-    const char* as = smem + (kt & 1) * 2 * TILE_BYTES;
-    const char* bs = as + TILE_BYTES;
+    auto stage = [&](int buf, int k0) {
+      char* as = smem + buf * 2 * TILE_BYTES + wave * 4096;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      Frag<T> fa[2], fb[2];
+      for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + TILE_BYTES + j * 1024), 16, 0, 0);
+      }
+    };
+    const int nk = p.K / 64;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * 64);
+      const char* as = smem + (kt & 1) * 2 * TILE_BYTES;
+      const char* bs = as + TILE_BYTES;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) nt_frag<T>(fa[i], as, wm * 64 + i * 32 + li, s, lh);
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> fa[2], fb[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
+        for (int i = 0; i < 2; ++i) nt_frag<T>(fa[i], as, wm * 64 + i * 32 + li, s, lh);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+      }
+      __syncthreads();   // drains this wave's LDS-DMA (vmcnt) and orders every wave's reads / DMA writes
     }
-    __syncthreads();   // drains this wave's LDS-DMA (vmcnt) and orders every wave's reads / DMA writes
+    nt_epilogue<T, TO>(p, acc, smem, m0, n0, wave, lane);
+    __syncthreads();     // epilogue staging region is reused by the next tile's operand DMA
   }
-  nt_epilogue<T, TO>(p, acc, smem, m0, n0, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ TN
@@ -536,8 +546,9 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   const size_t sh = 4 * TILE_BYTES;
   hipStream_t s = (hipStream_t)stream;
   const bool glds = dtype == FK_BF16 && (K % 64 == 0);
-  if (glds && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, block, sh, s, p);
-  else if (glds) hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, block, sh, s, p);
+  dim3 pgrid((unsigned)(nwg < 512 ? nwg : 512));           // persistent: 2 blocks per CU (64 KiB LDS each)
+  if (glds && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), pgrid, block, sh, s, p);
+  else if (glds) hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), pgrid, block, sh, s, p);
   else if (dtype == FK_BF16 && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, sh, s, p);
   else if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, sh, s, p);
   else hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, sh, s, p);
