@@ -53,8 +53,9 @@ struct NtArgs {
 
 // Epilogue shared by the NT kernels: acc are C^T tiles (lane = output row m, registers = 4 consecutive n).
 template <typename T, typename TO>
-FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int wave, int lane) {
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mrow0, int ncol0, int lane, bool sync) {
+  // acc = one wave's 64x64 sub-tile whose top-left output element is (mrow0, ncol0); stg = that wave's 16 KiB of LDS
+  const int li = lane & 31, lh = lane >> 5;
   const T* bias = (const T*)p.bias;
   const T* res = (const T*)p.res;
   TO* C = (TO*)p.C;
@@ -65,8 +66,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* smem, int m0
     // staged rows are 256 B (64 fp32), 16-byte chunk c of row r stored at chunk c ^ (r & 15): conflict-free for the
     // column-of-rows b128 writes and the row-sweep b128 reads; 4 waves x 16 KiB = the 64 KiB already allocated.
     auto eoff = [](int row, int colf) { return row * 256 + ((((colf >> 2) ^ (row & 15)) << 4) | ((colf & 3) << 2)); };
-    __syncthreads();                                // all waves finished reading the operand tiles
-    char* stg = smem + wave * (64 * 256);
+    if (sync) __syncthreads();                      // all waves finished reading the operand tiles
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -76,14 +76,14 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* smem, int m0
           f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
           *reinterpret_cast<f32x4*>(stg + eoff(i * 32 + li, j * 32 + 8 * g + 4 * lh)) = v;
         }
-    const int col = (lane & 7) * 8, nb = n0 + wn * 64 + col;
+    const int col = (lane & 7) * 8, nb = ncol0 + col;
     const bool col_ok = nb < p.N;                   // N % 8 == 0 on this path
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = (bias && col_ok) ? to_f32<T>(bias[nb + e]) : 0.0f;
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
-      const int row = ps * 8 + (lane >> 3), m = m0 + wm * 64 + row;
+      const int row = ps * 8 + (lane >> 3), m = mrow0 + row;
       f32x4 a = *reinterpret_cast<const f32x4*>(stg + eoff(row, col));
       f32x4 b = *reinterpret_cast<const f32x4*>(stg + eoff(row, col + 4));
       if (m < p.M && col_ok) {
@@ -177,14 +177,14 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* smem, int m0
   // scalar epilogue (any N / ldc): lane = output row m, registers = columns n
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + li;
+    const int m = mrow0 + i * 32 + li;
     if (m >= p.M) continue;
     const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + j * 32 + acc_row(r, lh);
+        const int n = ncol0 + j * 32 + acc_row(r, lh);
         if (n >= p.N) continue;
         float v = acc[i][j][r] + (bias ? to_f32<T>(bias[n]) : 0.0f);
         if (res) v += to_f32<T>(res[rr * p.ldr + n]);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs p) {
     __syncthreads();
   }
 
-  nt_epilogue<T, TO>(p, acc, smem, m0, n0, wave, lane);
+  nt_epilogue<T, TO>(p, acc, smem + wave * 16384, m0 + (wave >> 1) * 64, n0 + (wave & 1) * 64, lane, true);
 }
 
 // bf16 fast path: operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 8 image rows per wave
@@ -335,8 +335,90 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(NtArgs p) {
       }
       __syncthreads();   // drains this wave's LDS-DMA (vmcnt) and orders every wave's reads / DMA writes
     }
-    nt_epilogue<T, TO>(p, acc, smem, m0, n0, wave, lane);
+    nt_epilogue<T, TO>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane, true);
     __syncthreads();     // epilogue staging region is reused by the next tile's operand DMA
+  }
+}
+
+// Large-tile variant for the big projections: 256 x BN_ block tile (BN_ = 256 or 128), 8 waves (2 per SIMD), wave tile
+// (256/WROWS) x 64.  A 128x128 tile needs 64 B of L2->LDS traffic per MFMA cycle per CU at full rate, more than the L2
+// fabric delivers (measured ~8 TB/s chip-wide on the small-tile kernel); 256x256 halves that (32 B/cycle) and gives each
+// LDS-DMA a whole k-tile of two waves' MFMAs (2 x 1024 cycles per SIMD) to land.  Same image / swizzle / epilogue code.
+template <typename TO, int BN_>
+__global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
+  using T = bf16_t;
+  constexpr int BM_ = 256, WCOLS = BN_ / 64, WROWS = 8 / WCOLS, WM = BM_ / WROWS, MT = WM / 32;
+  constexpr int A_BYTES = BM_ * ROW_BYTES, B_BYTES = BN_ * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PER_WAVE = BM_ / 64, B_PER_WAVE = BN_ / 64;     // 1-KiB DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WCOLS, wn = wave % WCOLS, li = lane & 31, lh = lane >> 5;
+  const int ntn = (p.N + BN_ - 1) / BN_;
+  const int ntiles = ((p.M + BM_ - 1) / BM_) * ntn;
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = (nb + 7 - xcd) >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int t_beg = xcd * q8 + min(xcd, r8), t_end = t_beg + q8 + (xcd < r8 ? 1 : 0);
+
+  for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
+    const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const T* srcA[A_PER_WAVE];
+    const T* srcB[B_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+      const int row = (wave * A_PER_WAVE + j) * 8 + (lane >> 3);
+      srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) {
+      const int row = (wave * B_PER_WAVE + j) * 8 + (lane >> 3);
+      srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+      char* as = smem + buf * STAGE;
+#pragma unroll
+      for (int j = 0; j < A_PER_WAVE; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + (wave * A_PER_WAVE + j) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < B_PER_WAVE; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + A_BYTES + (wave * B_PER_WAVE + j) * 1024), 16, 0, 0);
+    };
+    const int nk = p.K / 64;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * 64);
+      const char* as = smem + (kt & 1) * STAGE;
+      const char* bs = as + A_BYTES;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> fa[MT], fb[2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) nt_frag<T>(fa[i], as, wm * WM + i * 32 + li, s, lh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+      }
+      __syncthreads();
+    }
+    // epilogue: 64-row halves of the wave tile through this wave's 16 KiB staging slice (8 x 16 KiB <= 2 * STAGE)
+#pragma unroll
+    for (int hh = 0; hh < MT / 2; ++hh) {
+      f32x16 (&sub)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * hh][0]);
+      nt_epilogue<T, TO>(p, sub, smem + wave * 16384, m0 + wm * WM + hh * 64, n0 + wn * 64, lane, false);
+    }
+    __syncthreads();
   }
 }
 
@@ -546,6 +628,27 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   const size_t sh = 4 * TILE_BYTES;
   hipStream_t s = (hipStream_t)stream;
   const bool glds = dtype == FK_BF16 && (K % 64 == 0);
+  if (glds && M >= 4096 && N % 256 == 0 && vec_epi) {         // large projections: 256 x 256 tiles, 1 block per CU (the 256x128
+                                                                // variant measured slower than 128x128 at N = 384)
+    const bool wide = (N % 256 == 0);
+    const int bn = wide ? 256 : 128;
+    const int64_t nt = fk_cdiv(M, 256) * (N / bn);
+    dim3 bgrid((unsigned)(nt < 256 ? nt : 256)), bblock(512);
+    const size_t bsh = 2 * (size_t)(256 + bn) * ROW_BYTES;
+    if (wide) {
+      if (out_dtype == FK_BF16) { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<bf16_t, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true); (void)once;
+        hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 256>), bgrid, bblock, bsh, s, p); }
+      else { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<float, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true); (void)once;
+        hipLaunchKernelGGL((gemm_nt_big_kernel<float, 256>), bgrid, bblock, bsh, s, p); }
+    } else {
+      if (out_dtype == FK_BF16) { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<bf16_t, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true); (void)once;
+        hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 128>), bgrid, bblock, bsh, s, p); }
+      else { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<float, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true); (void)once;
+        hipLaunchKernelGGL((gemm_nt_big_kernel<float, 128>), bgrid, bblock, bsh, s, p); }
+    }
+    FK_CHECK_LAUNCH(name);
+    return FK_OK;
+  }
   dim3 pgrid((unsigned)(nwg < 512 ? nwg : 512));           // persistent: 2 blocks per CU (64 KiB LDS each)
   if (glds && out_dtype == FK_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), pgrid, block, sh, s, p);
   else if (glds) hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), pgrid, block, sh, s, p);
