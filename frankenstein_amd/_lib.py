@@ -21,6 +21,7 @@ SIGNATURES = {
     "fk_version": (_int, []),
     "fk_last_error": (C.c_char_p, []),
     "fk_gemm_nt": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _int, _int, _p]),
+    "fk_gemm_nt_rope": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_nt_swiglu": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_nt_dswiglu": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
@@ -28,7 +29,7 @@ SIGNATURES = {
     "fk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "fk_colsum": (_int, [_p, _i64, _p, _i64, _i64, _int, _int, _p, _sz, _p]),
     "fk_attn_fwd": (_int, [_p, _p, _p, _p, _p] + [_i64] * 13 + [_int, _i64, _i64, _i64, _f32, _int, _p]),
-    "fk_attn_bwd": (_int, [_p] * 10 + [_i64] * 13 + [_int, _i64, _i64, _i64, _f32, _int, _p]),
+    "fk_attn_bwd": (_int, [_p] * 10 + [_i64] * 13 + [_int, _i64, _i64, _i64, _f32, _p, _i64, _i64, _int, _p]),
     "fk_norm_fwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _int, _int, _p]),
     "fk_norm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "fk_norm_bwd": (_int, [_p] * 9 + [_i64, _i64, _int, _int, _int, _p, _sz, _p]),

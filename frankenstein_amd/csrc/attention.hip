@@ -35,6 +35,8 @@ struct AttnArgs {
   int B, H, Nq, Nk;
   int mask_kind, mask_c, q_off, k_off;
   float scale;
+  // backward only: inverse RoPE (rotation by -angle) applied to dQ / dK as they are stored (fuses the rope backward)
+  const float* rope_table; int64_t rope_bs; int rope_off;
 };
 
 template <typename T, int D> struct AT {
@@ -214,6 +216,32 @@ FK_DEV void store_rows_T(T* base, int64_t rs, int row, bool row_ok, const f32x16
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[dt][4 * g + j] * mul;
           *reinterpret_cast<f32x4*>(dst) = v;
+        }
+      }
+    }
+}
+
+// dQ / dK store with the inverse RoPE: pairs (d, d+1) of row `row` (sequence position rope_off + row) rotated by -angle
+template <typename T, int D>
+FK_DEV void store_rows_T_rope(T* base, int64_t rs, int row, bool row_ok, const f32x16 (&acc)[AT<T, D>::DT], float mul, int lh,
+                              const float* table) {   // table -> (cos, sin) pairs of this row: [D/2][2]
+  if (!row_ok) return;
+#pragma unroll
+  for (int dt = 0; dt < AT<T, D>::DT; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = dt * 32 + 8 * g + 4 * lh;
+      if (d < D) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(table + d);   // (c0, s0, c1, s1) for pairs d/2, d/2+1
+        const float a0 = acc[dt][4 * g] * mul, a1 = acc[dt][4 * g + 1] * mul, a2 = acc[dt][4 * g + 2] * mul, a3 = acc[dt][4 * g + 3] * mul;
+        const float o0 = a0 * cs[0] + a1 * cs[1], o1 = -a0 * cs[1] + a1 * cs[0];
+        const float o2 = a2 * cs[2] + a3 * cs[3], o3 = -a2 * cs[3] + a3 * cs[2];
+        T* dst = base + (int64_t)row * rs + d;
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 v = {(bf16_t)o0, (bf16_t)o1, (bf16_t)o2, (bf16_t)o3};
+          *reinterpret_cast<bf16x4*>(dst) = v;
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{o0, o1, o2, o3};
         }
       }
     }
@@ -504,7 +532,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
     __syncthreads();
   }
   T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
-  store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
+  if (p.rope_table && q_ok)
+    store_rows_T_rope<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + qrow) * D);
+  else
+    store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
 }
 
 // ================================================================================================= dK, dV
@@ -692,7 +723,10 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   }
   T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
   T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
-  store_rows_T<T, D>(dKp, p.k_rs, krow, k_ok, dk, p.scale, lh);
+  if (p.rope_table && k_ok)
+    store_rows_T_rope<T, D>(dKp, p.k_rs, krow, k_ok, dk, p.scale, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + krow) * D);
+  else
+    store_rows_T<T, D>(dKp, p.k_rs, krow, k_ok, dk, p.scale, lh);
   store_rows_T<T, D>(dVp, p.v_rs, krow, k_ok, dv, 1.0f, lh);
 }
 
@@ -787,8 +821,8 @@ int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
 int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                 void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                 int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
-                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, float scale, int dtype,
-                void* stream) {
+                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, float scale,
+                const float* rope_table, int64_t rope_bs, int64_t rope_off, int dtype, void* stream) {
   const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
   int rc = check_common("fk_attn_bwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
   if (rc) return rc;
@@ -801,6 +835,8 @@ int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
   a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
   a.B = (int)B; a.H = (int)H; a.Nq = (int)Nq; a.Nk = (int)Nk;
   a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
+  FK_CHECK_ARG(!rope_table || (Nq == Nk && D % 4 == 0 && ((uintptr_t)rope_table & 15) == 0), "fk_attn_bwd: fused inverse RoPE needs self-attention (Nq == Nk)");
+  a.rope_table = rope_table; a.rope_bs = rope_bs; a.rope_off = (int)rope_off;
   FK_ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_bwd");
   return FK_OK;

@@ -49,6 +49,9 @@ struct NtArgs {
   int M, N, K, vec_epi;
   int mode;            // 0 plain, 1 SwiGLU forward (also writes g), 2 SwiGLU backward (acc = dg -> writes dh13)
   void* aux; int64_t ldaux;
+  // fused RoPE on the first rope_cols output columns (q and k of a packed qkv projection): row m is token
+  // (m % rope_T) of its sample, rotated by table[(rope_off + m % rope_T)][(n % rope_D) / 2] = (cos, sin)
+  const float* rope_table; int64_t rope_bs; int rope_T, rope_off, rope_D, rope_cols;
 };
 
 // Epilogue shared by the NT kernels: acc are C^T tiles (lane = output row m, registers = 4 consecutive n).
@@ -99,6 +102,18 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mro
             f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+        }
+        if (p.rope_table && nb < p.rope_cols) {
+          const int tt = m % p.rope_T, bb = m / p.rope_T, dd = nb % p.rope_D;
+          const float* tb = p.rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 4);
+          const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float re = v[2 * j], im = v[2 * j + 1];
+            v[2 * j] = re * cs[2 * j] - im * cs[2 * j + 1];
+            v[2 * j + 1] = re * cs[2 * j + 1] + im * cs[2 * j];
           }
         }
         if (p.mode == 2) {
@@ -605,9 +620,11 @@ int colsum_blocks(int64_t rows) {
 
 extern "C" {
 
+struct RopeSpec { const float* table; int64_t bs; int T, off, D, cols; };
+
 static int launch_nt(const char* name, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                      int64_t N, int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
-                     int out_dtype, int mode, void* aux, int64_t ldaux, void* stream) {
+                     int out_dtype, int mode, void* aux, int64_t ldaux, void* stream, RopeSpec rope = RopeSpec{nullptr, 0, 1, 0, 2, 0}) {
   FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "%s: bad dtype %d", name, dtype);
   FK_CHECK_ARG(out_dtype == dtype || out_dtype == FK_F32, "%s: out_dtype must equal dtype or be f32", name);
   const int vec = dtype == FK_BF16 ? 8 : 4;
@@ -622,7 +639,11 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   if (mode != 0)
     FK_CHECK_ARG(vec_epi && out_dtype == dtype && aux && ldaux % ovec == 0 && ((uintptr_t)aux & 15) == 0,
                  "%s: fused SwiGLU epilogue needs N %% 8 == 0 and 16-byte aligned, 8-element strided buffers", name);
-  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K, vec_epi ? 1 : 0, mode, aux, ldaux};
+  if (rope.table)
+    FK_CHECK_ARG(vec_epi && rope.D % 8 == 0 && rope.cols % rope.D == 0 && rope.cols <= N && rope.T > 0 && M % rope.T == 0 &&
+                 ((uintptr_t)rope.table & 15) == 0, "%s: fused RoPE needs the vector epilogue, D %% 8 == 0 and M %% T == 0", name);
+  NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K, vec_epi ? 1 : 0, mode, aux, ldaux,
+           rope.table, rope.bs, rope.T, rope.off, rope.D, rope.cols};
   const int64_t nwg = fk_cdiv(M, BM) * fk_cdiv(N, BN);
   dim3 grid((unsigned)nwg), block(NTHREADS);
   const size_t sh = 4 * TILE_BYTES;
@@ -663,6 +684,14 @@ int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
                int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
                int out_dtype, void* stream) {
   return launch_nt("fk_gemm_nt", A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_rows, dtype, out_dtype, 0, nullptr, 0, stream);
+}
+
+int fk_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, const void* bias, const float* table, int64_t table_bs, int64_t T, int64_t pos_off, int64_t D,
+                    int64_t rot_cols, int dtype, void* stream) {
+  FK_CHECK_ARG(table && T > 0 && D > 0 && rot_cols >= 0, "fk_gemm_nt_rope: bad rope arguments");
+  return launch_nt("fk_gemm_nt_rope", A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, 0, dtype, dtype, 0, nullptr, 0, stream,
+                   RopeSpec{table, table_bs, (int)T, (int)pos_off, (int)D, (int)rot_cols});
 }
 
 int fk_gemm_nt_swiglu(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G,

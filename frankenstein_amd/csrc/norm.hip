@@ -288,19 +288,21 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const 
   for (int i = threadIdx.x; i < 2 * dim; i += blockDim.x)
     part[(int64_t)blockIdx.x * 2 * dim + i] = red[i] + red[2 * dim + i] + red[4 * dim + i] + red[6 * dim + i];
 }
-// out[which][c] = sum_k part[k][which][c]; block = 64 columns x 4 slices
-__global__ __launch_bounds__(256) void norm_bwd_fused_final(const float* part, float* dgamma, float* dbeta, int dim, int nblk, int accumulate) {
-  __shared__ float sh[4][64];
+// out[which][c] = sum_k part[k][which][c]; block = 64 columns x 16 slices (short dependent chains)
+__global__ __launch_bounds__(1024) void norm_bwd_fused_final(const float* part, float* dgamma, float* dbeta, int dim, int nblk, int accumulate) {
+  __shared__ float sh[16][64];
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, which = blockIdx.y;
   float s = 0.0f;
   if (c < dim)
-    for (int k = sl; k < nblk; k += 4) s += part[((int64_t)k * 2 + which) * dim + c];
+    for (int k = sl; k < nblk; k += 16) s += part[((int64_t)k * 2 + which) * dim + c];
   sh[sl][cl] = s;
   __syncthreads();
   if (sl == 0 && c < dim) {
     float* out = which == 0 ? dgamma : dbeta;
     if (out) {
-      const float t = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += sh[i][cl];
       out[c] = accumulate ? out[c] + t : t;
     }
   }
@@ -427,7 +429,7 @@ int fk_norm_bwd(const void* dy, const void* x, const float* gamma, const float* 
 #undef FK_NB
     FK_CHECK_LAUNCH("fk_norm_bwd(fused)");
     if (want) {
-      hipLaunchKernelGGL(norm_bwd_fused_final, dim3((unsigned)fk_cdiv(dim, 64), 2), dim3(256), 0, s, (const float*)part, dgamma, dbeta, (int)dim, (int)nbf, accumulate);
+      hipLaunchKernelGGL(norm_bwd_fused_final, dim3((unsigned)fk_cdiv(dim, 64), 2), dim3(1024), 0, s, (const float*)part, dgamma, dbeta, (int)dim, (int)nbf, accumulate);
       FK_CHECK_LAUNCH("fk_norm_bwd(fused final)");
     }
     return FK_OK;

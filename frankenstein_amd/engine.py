@@ -180,11 +180,16 @@ class AttnBranch(torch.autograd.Function):
             h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps)
         else:
             h, mean, rstd = x2, None, None
-        qkv = K.gemm_nt(h, shadow(qkv_w), bias=None if qkv_b is None else shadow([qkv_b]))
         HD = H * D
-        qkv3 = qkv.view(B, N, 3 * HD)
-        if rope is not None:
-            K.rope_(qkv3, 2 * H, D, rope.table, rope.pos_off(N))
+        bq = None if qkv_b is None else shadow([qkv_b])
+        if rope is not None and D % 8 == 0 and (3 * HD) % 8 == 0:     # RoPE fused into the projection epilogue
+            qkv = K.gemm_nt_rope(h, shadow(qkv_w), bq, rope.table, N, rope.pos_off(N), D, 2 * HD)
+            qkv3 = qkv.view(B, N, 3 * HD)
+        else:
+            qkv = K.gemm_nt(h, shadow(qkv_w), bias=bq)
+            qkv3 = qkv.view(B, N, 3 * HD)
+            if rope is not None:
+                K.rope_(qkv3, 2 * H, D, rope.table, rope.pos_off(N))
         q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
         o, lse = K.attn_fwd(q, k, v, mask)
         y = K.gemm_nt(o.view(M, HD), shadow([pw]), bias=None if pb is None else shadow([pb]),
@@ -215,9 +220,12 @@ class AttnBranch(torch.autograd.Function):
         qkv3, dqkv3 = qkv.view(B, N, 3 * HD), dqkv.view(B, N, 3 * HD)
         q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
         dq, dk, dv = (dqkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
-        K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask)
-        if rope is not None:
-            K.rope_(dqkv3, 2 * H, D, rope.table, rope.pos_off(N), conj=True)
+        if rope is not None and D % 4 == 0:       # inverse RoPE fused into the dQ / dK stores
+            K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask, rope_table=rope.table, rope_off=rope.pos_off(N))
+        else:
+            K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask)
+            if rope is not None:
+                K.rope_(dqkv3, 2 * H, D, rope.table, rope.pos_off(N), conj=True)
         dh = K.gemm_nt(dqkv, shadow(qkv_w, transpose=True))
         dw = K.gemm_tn(dqkv, h)
         dqb = K.colsum(dqkv) if has_qb else None

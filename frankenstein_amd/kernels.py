@@ -91,6 +91,22 @@ def gemm_nt(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
     return out
 
 
+def gemm_nt_rope(a: Tensor, w: Tensor, bias: Optional[Tensor], table: Tensor, T: int, pos_off: int, D: int,
+                 rot_cols: int) -> Tensor:
+    """out[M,N] = a @ w^T (+ bias) with RoPE applied to the first rot_cols columns (heads of width D); rows are B x T tokens."""
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[-1] == 2 and table.shape[-2] == D // 2
+    M, Kd = a.shape
+    N = w.shape[0]
+    tbs = table.stride(0) if table.dim() == 4 else 0
+    assert pos_off >= 0 and pos_off + T <= table.shape[-3] and M % T == 0
+    out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    with _timed(f"gemm_nt_rope:{M}x{N}x{Kd}"):
+        call("fk_gemm_nt_rope", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), N, M, N, Kd, _ptr(bias),
+             table.data_ptr(), tbs, T, pos_off, D, rot_cols, fk_dtype(a), _stream())
+    return out
+
+
 def gemm_nt_swiglu(a: Tensor, w13: Tensor) -> Tuple[Tensor, Tensor]:
     """(h13 [M, 2H] interleaved, g [M, H]) = fused up-projection + SwiGLU; w13 is the interleaved [2H, K] shadow."""
     assert a.dim() == 2 and w13.dim() == 2 and a.shape[1] == w13.shape[1] and a.dtype == w13.dtype
@@ -188,8 +204,9 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optio
 
 
 def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
-             mask: Mask = NO_MASK, scale: Optional[float] = None) -> None:
-    """Writes dq/dk/dv (same strides as q/k/v); do must have o's strides."""
+             mask: Mask = NO_MASK, scale: Optional[float] = None, rope_table: Optional[Tensor] = None,
+             rope_off: int = 0) -> None:
+    """Writes dq/dk/dv (same strides as q/k/v); do must have o's strides.  rope_table: also un-rotate dq/dk (RoPE backward)."""
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     (qb, qr), (kb, kr), (vb, vr), (ob, orr) = _bnhd(q), _bnhd(k), _bnhd(v), _bnhd(o)
@@ -200,7 +217,8 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     with _timed(f"attn_bwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
       call("fk_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
-           mask.kind, mask.c, mask.q_off, mask.k_off, sc, fk_dtype(q), _stream())
+           mask.kind, mask.c, mask.q_off, mask.k_off, sc, _ptr(rope_table),
+           0 if rope_table is None or rope_table.dim() == 3 else rope_table.stride(0), rope_off, fk_dtype(q), _stream())
 
 
 # ------------------------------------------------------------------------------------------- norms

@@ -46,6 +46,12 @@ const char* fk_last_error(void);
 int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
                int out_dtype, void* stream);
+/* fk_gemm_nt_rope: fk_gemm_nt (+ bias) with apply_rope (models/brainformer.py:70-91) fused into the epilogue: the first
+ * rot_cols output columns (q and k of a packed q|k|v projection, heads of width D) of row m are rotated by
+ * table[m / T][pos_off + m % T][(n % D) / 2] = (cos, sin)  (table_bs = 0: one cache shared by all samples).           */
+int fk_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, const void* bias, const float* table, int64_t table_bs, int64_t T, int64_t pos_off, int64_t D,
+                    int64_t rot_cols, int dtype, void* stream);
 /* SwiGLU MLP fused into the projection epilogues (models/brainformer.py:124 and its autograd).  Hidden units use the
  * INTERLEAVED layout: for every 4 hidden units, 4 columns of h1 = w1 x followed by 4 columns of h3 = w3 x (W13 rows are
  * packed the same way, see fk_cast_pack_rows).
@@ -70,7 +76,8 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
  * mask: NONE | CAUSAL (k + k_off <= q + q_off) | BLOCK_CAUSAL ((k + k_off)/mask_c <= (q + q_off)/mask_c), the
  * analytic form of build_advanced_causal_mask (models/brainformer.py:93-111) incl. the [-t_q:, -t_k:] slice (:160-162).
  * Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
- * Q/K/V's strides; delta_ws is [B,H,Nq] fp32 scratch.                                                        */
+ * Q/K/V's strides; delta_ws is [B,H,Nq] fp32 scratch.  rope_table != NULL (self-attention only) additionally applies the
+ * inverse RoPE (rotation by -angle at position rope_off + index) to dQ and dK as they are stored = apply_rope's backward.                                                        */
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
                 int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
                 int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
@@ -78,8 +85,8 @@ int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
 int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                 void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                 int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
-                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, float scale, int dtype,
-                void* stream);
+                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, float scale,
+                const float* rope_table, int64_t rope_bs, int64_t rope_off, int dtype, void* stream);
 
 /* ---- normalisation (nn.LayerNorm: models/brainformer.py:237,239,252,254,287,500; F.layer_norm models/gpt2_model.py:27;
  *      RMSNorm models/brainformer.py:221-232).  x,y [rows, dim] contiguous; gamma/beta fp32 (beta may be NULL);

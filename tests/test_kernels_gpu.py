@@ -387,3 +387,27 @@ def test_fused_swiglu_gemms(K, dtype):
         assert torch.equal(a.cpu(), ref[:, 0].reshape(H, 8)) and torch.equal(b.cpu(), ref[:, 1].reshape(H, 8))
     finally:
         E.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_fused_rope_projection_and_backward(K, dtype):
+    """RoPE fused into the q|k|v projection epilogue, and its inverse fused into the attention-backward dQ/dK stores."""
+    B, T, H, D, d = 2, 40, 3, 16, 64
+    ang = R.rope_angles(D, 64, 10000.0)
+    table = torch.stack([torch.cos(ang), torch.sin(ang)], -1).contiguous()
+    x, w, bias = rnd(B * T, d, seed=1), rnd(3 * H * D, d, seed=2, scale=0.2), rnd(3 * H * D, seed=3, scale=0.1)
+    got = K.gemm_nt_rope(dev(x, dtype), dev(w, dtype), dev(bias, dtype), dev(table), T, 64 - T, D, 2 * H * D)
+    ref = (q(x, dtype) @ q(w, dtype).t() + q(bias, dtype)).view(B, T, 3 * H * D)
+    ref[..., : 2 * H * D] = R.apply_rope(ref[..., : 2 * H * D].reshape(B, T, 2 * H, D), ang).reshape(B, T, -1)
+    close(got.view(B, T, -1), ref, dtype, atol32=2e-5, atol16=3e-2)
+    # backward: attn_bwd with rope_table == attn_bwd then conj-rope on dq, dk
+    qkv = dev(rnd(B, T, 3 * H * D, seed=4), dtype)
+    qv, kv, vv = (qkv[..., i * H * D:(i + 1) * H * D].unflatten(-1, (H, D)) for i in range(3))
+    o, lse = K.attn_fwd(qv, kv, vv, K.Mask(1))
+    do = dev(rnd(B, T, H, D, seed=5), dtype)
+    d1, d2 = torch.empty_like(qkv), torch.empty_like(qkv)
+    views = lambda t: [t[..., i * H * D:(i + 1) * H * D].unflatten(-1, (H, D)) for i in range(3)]
+    K.attn_bwd(qv, kv, vv, o, do, lse, *views(d1), K.Mask(1))
+    K.rope_(d1, 2 * H, D, dev(table), 64 - T, conj=True)
+    K.attn_bwd(qv, kv, vv, o, do, lse, *views(d2), K.Mask(1), rope_table=dev(table), rope_off=64 - T)
+    close(d2, d1.float().cpu(), dtype, atol32=1e-6, atol16=3e-2)
