@@ -138,6 +138,25 @@ template <typename T, int D> FK_DEV void img_tr(Frag<T>& f, const char* img, int
   }
 }
 
+// LDS-DMA (global_load_lds_dwordx4) loader for a [ROWS][64] bf16 head tile in the Img<bf16,64> layout: one wave
+// instruction fills 8 image rows (1 KiB, lane-linear), so the chunk swizzle is applied to the per-lane source address.
+// Rows past nrows are clamped to the last valid row (finite data; the mask / LSE=+inf zeroes their contribution).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+template <int ROWS, int NW = 4>
+FK_DEV void dma_tile_bf16_d64(const bf16_t* base, int64_t rs, int row0, int nrows, char* img, int wave, int lane) {
+  constexpr int PER_WAVE = ROWS / 8 / NW;   // wave instructions per wave
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int grp = wave * PER_WAVE + j;               // 8-row group
+    const int row = grp * 8 + (lane >> 3);
+    const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+    const int ch = (lane & 7) ^ f;                     // logical chunk stored at physical chunk (lane & 7)
+    const bf16_t* src = base + (int64_t)min(row0 + row, nrows - 1) * rs + ch * 8;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(img + grp * 1024), 16, 0, 0);
+  }
+}
+
 // ---- global -> register -> LDS staging of a [ROWS][D] head tile -----------------------------------
 template <typename T, int D, int ROWS> struct Stager {
   using C = AT<T, D>;
@@ -168,25 +187,6 @@ template <typename T, int D, int ROWS> struct Stager {
     }
   }
 };
-
-// LDS-DMA (global_load_lds_dwordx4) loader for a [ROWS][64] bf16 head tile in the Img<bf16,64> layout: one wave
-// instruction fills 8 image rows (1 KiB, lane-linear), so the chunk swizzle is applied to the per-lane source address.
-// Rows past nrows are clamped to the last valid row (finite data; the mask / LSE=+inf zeroes their contribution).
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
-template <int ROWS>
-FK_DEV void dma_tile_bf16_d64(const bf16_t* base, int64_t rs, int row0, int nrows, char* img, int wave, int lane) {
-  constexpr int PER_WAVE = ROWS / 8 / 4;   // wave instructions per wave
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int grp = wave * PER_WAVE + j;               // 8-row group
-    const int row = grp * 8 + (lane >> 3);
-    const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
-    const int ch = (lane & 7) ^ f;                     // logical chunk stored at physical chunk (lane & 7)
-    const bf16_t* src = base + (int64_t)min(row0 + row, nrows - 1) * rs + ch * 8;
-    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(img + grp * 1024), 16, 0, 0);
-  }
-}
 
 template <int N> FK_DEV void zero_acc(f32x16 (&a)[N]) {
 #pragma unroll
@@ -248,13 +248,18 @@ FK_DEV void store_rows_T_rope(T* base, int64_t rs, int row, bool row_ok, const f
 }
 
 // ================================================================================================= forward
-template <typename T, int D>
-__global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
+// NW waves per workgroup (32 query rows each).  The DMA path runs 8 waves = 256 query rows per workgroup: every K/V tile
+// fetched from L2 then feeds twice the MFMA work (the 128-row version sat on the L2->LDS bandwidth ceiling).
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   using C = AT<T, D>;
+  constexpr int BQ = NW * 32, NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KIMG = BKV * C::RSTRIDE, VIMG = BKV * C::VSTRIDE;
+  constexpr bool DMA = Img<T, D>::SWZ;   // bf16, D = 64: swizzled 128-B-row images filled by LDS-DMA
+  constexpr int KIMG = DMA ? BKV * 128 : BKV * C::RSTRIDE, VIMG = DMA ? BKV * 128 : BKV * C::VSTRIDE;
+  constexpr int NSLOT = DMA ? 3 : 2;      // DMA path: 3-slot ring, tiles t+1 and t+2 in flight while tile t is consumed
   auto kimg = [&](int i) -> char* { return smem + i * KIMG; };
-  auto vimg = [&](int i) -> char* { return smem + 2 * KIMG + i * VIMG; };
+  auto vimg = [&](int i) -> char* { return smem + NSLOT * KIMG + i * VIMG; };
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile predicates become scalar branches
   // 1-D grid, XCD-aware: each XCD walks whole (batch, head) pairs (their K/V stay in its L2), heaviest
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
   const bool q_ok = qrow < p.Nq;
 
   if constexpr (C::DPAD != D) {   // zero the padded columns of the K/V images once (never restaged)
-    for (int i = tid; i < (2 * KIMG + 2 * VIMG) / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
+    for (int i = tid; i < (NSLOT * KIMG + NSLOT * VIMG) / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
     __syncthreads();
   }
 
@@ -287,32 +292,61 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
   const int full_vis_end = kv_limit(p, wave_q_first);
 
-  Stager<T, D, BKV> sk, sv;
-  if (ntiles > 0) {
-    sk.load(Kp, p.k_rs, 0, p.Nk, tid);
-    sv.load(Vp, p.v_rs, 0, p.Nk, tid);
-    sk.store(kimg(0), C::RSTRIDE, tid);
-    sv.store(vimg(0), C::VSTRIDE, tid);
+  Stager<T, D, DMA ? 4 : BKV> sk, sv;
+  if constexpr (DMA) {
+    // the register-resident Q fragments must be complete before the ring starts: from here on vmcnt counts only
+    // LDS-DMA instructions (4 per wave and tile), which the loop retires with counted waits.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+      if (pt < ntiles) {
+        dma_tile_bf16_d64<BKV, NW>((const bf16_t*)Kp, p.k_rs, pt * BKV, p.Nk, kimg(pt), wave, lane);
+        dma_tile_bf16_d64<BKV, NW>((const bf16_t*)Vp, p.v_rs, pt * BKV, p.Nk, vimg(pt), wave, lane);
+      }
+  } else {
+    if (ntiles > 0) {
+      sk.load(Kp, p.k_rs, 0, p.Nk, tid);
+      sv.load(Vp, p.v_rs, 0, p.Nk, tid);
+      sk.store(kimg(0), C::RSTRIDE, tid);
+      sv.store(vimg(0), C::VSTRIDE, tid);
+    }
+    __syncthreads();
+    // Everything loaded so far (the register-resident fragments) is complete before the loop: tells hipcc's waitcnt
+    // pass that the MFMA operands are ready, so inside the loop it waits only for LDS reads and the prefetched tile's
+    // global loads stay in flight behind the MFMAs (otherwise it re-waits vmcnt at the first MFMA of every iteration).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   }
-  __syncthreads();
-
-  // Everything loaded so far (the register-resident fragments) is complete before the loop: tells hipcc's waitcnt
-  // pass that the MFMA operands are ready, so inside the loop it waits only for LDS reads and the prefetched tile's
-  // global loads stay in flight behind the MFMAs (otherwise it re-waits vmcnt at the first MFMA of every iteration).
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   const float c = p.scale * LOG2E;
   float m = -INFINITY, l = 0.0f;
   f32x16 o[C::DT];
   zero_acc(o);
 
+  int slot = 0;
   for (int t = 0; t < ntiles; ++t) {
     const int kb = t * BKV;
-    if (t + 1 < ntiles) {
-      sk.load(Kp, p.k_rs, kb + BKV, p.Nk, tid);
-      sv.load(Vp, p.v_rs, kb + BKV, p.Nk, tid);
+    if constexpr (DMA) {
+      // retire tile t's DMA (oldest 4 of this wave) but leave tile t+1's in flight across the barrier; the barrier also
+      // guarantees every wave is done reading slot (t+2)%3 (= tile t-1), which is refilled right after it.
+      if (t + 1 < ntiles) {
+        if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      if (t + 1 >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + 2 < ntiles) {
+        const int ns = slot >= 1 ? slot - 1 : 2;     // (t + 2) % 3
+        dma_tile_bf16_d64<BKV, NW>((const bf16_t*)Kp, p.k_rs, kb + 2 * BKV, p.Nk, kimg(ns), wave, lane);
+        dma_tile_bf16_d64<BKV, NW>((const bf16_t*)Vp, p.v_rs, kb + 2 * BKV, p.Nk, vimg(ns), wave, lane);
+      }
+    } else {
+      if (t + 1 < ntiles) {
+        sk.load(Kp, p.k_rs, kb + BKV, p.Nk, tid);
+        sv.load(Vp, p.v_rs, kb + BKV, p.Nk, tid);
+      }
     }
-    const char* kt = kimg(t & 1);
-    const char* vt = vimg(t & 1);
+    const char* kt = kimg(DMA ? slot : (t & 1));
+    const char* vt = vimg(DMA ? slot : (t & 1));
     f32x16 sc[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -321,7 +355,8 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int s = 0; s < C::KSTEPS; ++s) {
         Frag<T> kf;
-        frag_row<T>(kf, kt, C::RSTRIDE, 32 * u + li, s, lh);
+        if constexpr (DMA) img_row<T, D>(kf, kt, 32 * u + li, s, lh);
+        else frag_row<T>(kf, kt, C::RSTRIDE, 32 * u + li, s, lh);
         mma32<T>(sc[u], kf, qf[s]);
       }
     }
@@ -373,15 +408,20 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
           Frag<T> vf;
-          frag_tr<T>(vf, vt, C::VSTRIDE, 32 * u, s, 32 * dt, lane);
+          if constexpr (DMA) img_tr<T, D>(vf, vt, 32 * u, s, 32 * dt, lane);
+          else frag_tr<T>(vf, vt, C::VSTRIDE, 32 * u, s, 32 * dt, lane);
           mma32<T>(o[dt], vf, pf);
         }
       }
-    if (t + 1 < ntiles) {
-      sk.store(kimg((t + 1) & 1), C::RSTRIDE, tid);
-      sv.store(vimg((t + 1) & 1), C::VSTRIDE, tid);
+    if constexpr (!DMA) {
+      if (t + 1 < ntiles) {
+        sk.store(kimg((t + 1) & 1), C::RSTRIDE, tid);
+        sv.store(vimg((t + 1) & 1), C::VSTRIDE, tid);
+      }
+      __syncthreads();
+    } else {
+      slot = slot == 2 ? 0 : slot + 1;
     }
-    __syncthreads();
   }
 
   const float lt = l + __shfl_xor(l, 32, 64);
@@ -464,12 +504,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
   const int full_vis_end = kv_limit(p, wave_q_first);
 
-  Stager<T, D, BKV> sk, sv;
+  constexpr bool DMA = Img<T, D>::SWZ;
+  Stager<T, D, DMA ? 4 : BKV> sk, sv;
   if (ntiles > 0) {
-    sk.load(Kp, p.k_rs, 0, p.Nk, tid);
-    sv.load(Vp, p.v_rs, 0, p.Nk, tid);
-    sk.store_img(kimg(0), tid);
-    sv.store(vimg(0), C::RSTRIDE, tid);
+    if constexpr (DMA) {
+      dma_tile_bf16_d64<BKV>((const bf16_t*)Kp, p.k_rs, 0, p.Nk, kimg(0), wave, lane);
+      dma_tile_bf16_d64<BKV>((const bf16_t*)Vp, p.v_rs, 0, p.Nk, vimg(0), wave, lane);
+    } else {
+      sk.load(Kp, p.k_rs, 0, p.Nk, tid);
+      sv.load(Vp, p.v_rs, 0, p.Nk, tid);
+      sk.store_img(kimg(0), tid);
+      sv.store(vimg(0), C::RSTRIDE, tid);
+    }
   }
   __syncthreads();
 
@@ -481,8 +527,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   for (int t = 0; t < ntiles; ++t) {
     const int kb = t * BKV;
     if (t + 1 < ntiles) {
-      sk.load(Kp, p.k_rs, kb + BKV, p.Nk, tid);
-      sv.load(Vp, p.v_rs, kb + BKV, p.Nk, tid);
+      if constexpr (DMA) {
+        dma_tile_bf16_d64<BKV>((const bf16_t*)Kp, p.k_rs, kb + BKV, p.Nk, kimg((t + 1) & 1), wave, lane);
+        dma_tile_bf16_d64<BKV>((const bf16_t*)Vp, p.v_rs, kb + BKV, p.Nk, vimg((t + 1) & 1), wave, lane);
+      } else {
+        sk.load(Kp, p.k_rs, kb + BKV, p.Nk, tid);
+        sv.load(Vp, p.v_rs, kb + BKV, p.Nk, tid);
+      }
     }
     const char* kt = kimg(t & 1);
     const char* vt = vimg(t & 1);
@@ -496,7 +547,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
       for (int s = 0; s < C::KSTEPS; ++s) {
         Frag<T> kf, vf;
         img_row<T, D>(kf, kt, 32 * u + li, s, lh);
-        frag_row<T>(vf, vt, C::RSTRIDE, 32 * u + li, s, lh);
+        if constexpr (DMA) img_row<T, D>(vf, vt, 32 * u + li, s, lh);
+        else frag_row<T>(vf, vt, C::RSTRIDE, 32 * u + li, s, lh);
         mma32<T>(sc, kf, qf[s]);
         mma32<T>(dp, vf, gf[s]);
       }
@@ -525,9 +577,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
         }
       }
     }
-    if (t + 1 < ntiles) {
-      sk.store_img(kimg((t + 1) & 1), tid);
-      sv.store(vimg((t + 1) & 1), C::RSTRIDE, tid);
+    if constexpr (!DMA) {
+      if (t + 1 < ntiles) {
+        sk.store_img(kimg((t + 1) & 1), tid);
+        sv.store(vimg((t + 1) & 1), C::RSTRIDE, tid);
+      }
     }
     __syncthreads();
   }
@@ -731,7 +785,9 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
 }
 
 // ------------------------------------------------------------------------------------------------- host
-template <typename T, int D> size_t fwd_lds() { return 2 * BKV * (AT<T, D>::RSTRIDE + AT<T, D>::VSTRIDE); }
+template <typename T, int D> size_t fwd_lds() {
+  return Img<T, D>::SWZ ? (size_t)3 * 2 * BKV * 128 : (size_t)2 * BKV * (AT<T, D>::RSTRIDE + AT<T, D>::VSTRIDE);
+}
 template <typename T, int D> size_t dq_lds() { return 4 * BKV * AT<T, D>::RSTRIDE; }
 template <typename T, int D> size_t dkdv_lds() { return 4 * 64 * AT<T, D>::RSTRIDE + 4 * 64 * sizeof(float); }
 
@@ -740,10 +796,11 @@ template <typename K> void allow_lds(K kernel, size_t bytes) {
 }
 
 template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
-  dim3 grid((unsigned)(((a.Nq + BQ - 1) / BQ) * a.H * a.B));
+  constexpr int NW = Img<T, D>::SWZ ? 8 : 4;
+  dim3 grid((unsigned)(((a.Nq + NW * 32 - 1) / (NW * 32)) * a.H * a.B));
   const size_t lds = fwd_lds<T, D>();
-  allow_lds(attn_fwd_kernel<T, D>, lds);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(NT), lds, s, a);
+  allow_lds(attn_fwd_kernel<T, D, NW>, lds);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D, NW>), grid, dim3(NW * 64), lds, s, a);
   return 0;
 }
 template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
