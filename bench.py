@@ -169,9 +169,16 @@ def main():
             bwd = name.startswith("attn_bwd")
             fl = attn_flops(B, 6, 6144, 6144, 64, 256, bwd)
             avg_s = tot / cnt / 1e3
-            roof = {"kernel": "fk_attn_bwd (delta + dK/dV + dQ kernels)" if bwd else "fk_attn_fwd",
+            traffic = None
+            try:   # HBM bytes per call from the committed rocprofv3 PMC passes (FETCH_SIZE x2 corrected + WRITE_SIZE)
+                pm = json.load(open(ROOT / "profiles" / "r01_pmc_traffic.json"))
+                traffic = pm["fk_attn_bwd_bytes_per_call"] if bwd else None
+            except Exception:
+                pass
+            roof = {"kernel": "fk_attn_bwd (attn_bwd_dkdv + attn_bwd_dq + attn_delta launches of one call)" if bwd else "fk_attn_fwd",
                     "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12,
-                    "unit": "TFLOP/s", "frac": round(fl / avg_s / MFMA_PEAK_BF16, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(fl / avg_s / MFMA_PEAK_BF16, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r01_pmc_traffic.json); algorithmic bytes 1.21e9",
                     "flops_per_launch": fl, "avg_launch_ms": round(avg_s * 1e3, 3)}
         out = {
             "metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "value": round(value, 1), "unit": "frames/s",
