@@ -260,6 +260,14 @@ def shard_batch(batch, rank: int, world: int):
     return tuple(t[rank * k:(rank + 1) * k] if torch.is_tensor(t) else t for t in batch)
 
 
+def save_model(model, path) -> None:
+    """safetensors checkpoint with the reference's key names (utils/train_utils.py:172).  Parameters are views into the
+    flat arena, which safetensors refuses to serialise as-is (shared storage), so tensors are cloned first."""
+    import safetensors.torch
+    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items() if v is not None}
+    safetensors.torch.save_file(sd, str(path))
+
+
 def run_train_model(model, datasets, config, project_name='transformer', save_folder=Path('logs'), logger=None):
     """Same contract as the reference: trains until max_steps, evaluates every eval_interval on the main process and
     saves the best model as safetensors.  Launch one process per GPU (torchrun) for data parallelism."""
@@ -304,7 +312,7 @@ def run_train_model(model, datasets, config, project_name='transformer', save_fo
                 if mean_val < best_val:
                     best_val = mean_val
                     path = save_folder / f"step_{overall_step}_loss_{mean_val:.4f}.safetensors"
-                    safetensors.torch.save_model(model, str(path))
+                    save_model(model, path)
                     print('saved model: ', path.name)
                 model.train()
             if overall_step > config.max_steps:
