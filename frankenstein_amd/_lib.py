@@ -11,7 +11,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libfranken_hip.so"
 
 FK_F32, FK_BF16 = 0, 1
-MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL = 0, 1, 2
+MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL, MASK_PREFIX = 0, 1, 2, 3
 NORM_LAYER, NORM_RMS = 0, 1
 
 _p, _i64, _int, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -28,8 +28,8 @@ SIGNATURES = {
     "fk_gemm_tn": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _int, _p, _sz, _p]),
     "fk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "fk_colsum": (_int, [_p, _i64, _p, _i64, _i64, _int, _int, _p, _sz, _p]),
-    "fk_attn_fwd": (_int, [_p, _p, _p, _p, _p] + [_i64] * 13 + [_int, _i64, _i64, _i64, _f32, _int, _p]),
-    "fk_attn_bwd": (_int, [_p] * 10 + [_i64] * 13 + [_int, _i64, _i64, _i64, _f32, _p, _i64, _i64, _int, _p]),
+    "fk_attn_fwd": (_int, [_p, _p, _p, _p, _p] + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _int, _p]),
+    "fk_attn_bwd": (_int, [_p] * 10 + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _p, _i64, _i64, _int, _p]),
     "fk_norm_fwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _int, _int, _p]),
     "fk_norm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "fk_norm_bwd": (_int, [_p] * 9 + [_i64, _i64, _int, _int, _int, _p, _sz, _p]),
@@ -43,6 +43,9 @@ SIGNATURES = {
     "fk_cast_pack_rows": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _i64, _i64, _i64, _int, _p]),
     "fk_cast": (_int, [_p, _int, _p, _int, _i64, _p]),
     "fk_add": (_int, [_p, _p, _p, _i64, _int, _p]),
+    "fk_gather_rows": (_int, [_p, _i64, _int, _p, _i64, _p, _i64, _int, _i64, _i64, _i64, _int, _p]),
+    "fk_scatter_add_rows": (_int, [_p, _int, _p, _i64, _p, _i64, _i64, _p]),
+    "fk_prefix_mask": (_int, [_p, _p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "fk_copy2d": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _p]),
     "fk_gpt_embed_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gpt_embed_bwd_wte": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),

@@ -37,6 +37,9 @@ struct AttnArgs {
   float scale;
   // backward only: inverse RoPE (rotation by -angle) applied to dQ / dK as they are stored (fuses the rope backward)
   const float* rope_table; int64_t rope_bs; int rope_off;
+  // FK_MASK_PREFIX: visible(q, k) = k < limits[b, q]  <=>  q >= qfirst[b, k]  (both non-decreasing; built by fk_prefix_mask
+  // from sorted per-token block ids: the per-sample sub-mask of MAE, models/brainformer.py:392-413)
+  const int* limits; const int* qfirst;
 };
 
 template <typename T, int D> struct AT {
@@ -58,14 +61,16 @@ FK_DEV bool visible(int kind, int c, int qpos, int kpos) {
   return true;
 }
 // exclusive upper bound of key INDICES visible to query index q (monotone predicates only)
-FK_DEV int kv_limit(const AttnArgs& p, int q) {
+FK_DEV int kv_limit(const AttnArgs& p, int b, int q) {
+  if (p.mask_kind == FK_MASK_PREFIX) return min(p.Nk, p.limits[(int64_t)b * p.Nq + q]);
   const int qpos = q + p.q_off;
   if (p.mask_kind == FK_MASK_CAUSAL) return min(p.Nk, max(0, qpos - p.k_off + 1));
   if (p.mask_kind == FK_MASK_BLOCK_CAUSAL) return min(p.Nk, max(0, (qpos / p.mask_c + 1) * p.mask_c - p.k_off));
   return p.Nk;
 }
 // smallest query INDEX that can see key index k
-FK_DEV int q_first(const AttnArgs& p, int k) {
+FK_DEV int q_first(const AttnArgs& p, int b, int k) {
+  if (p.mask_kind == FK_MASK_PREFIX) return p.qfirst[(int64_t)b * p.Nk + k];
   const int kpos = k + p.k_off;
   if (p.mask_kind == FK_MASK_CAUSAL) return max(0, kpos - p.q_off);
   if (p.mask_kind == FK_MASK_BLOCK_CAUSAL) return max(0, (kpos / p.mask_c) * p.mask_c - p.q_off);
@@ -272,6 +277,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
   const int qrow = q0 + wave * 32 + li;
   const bool q_ok = qrow < p.Nq;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX;
+  const int my_lim = (prefix && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;
 
   if constexpr (C::DPAD != D) {   // zero the padded columns of the K/V images once (never restaged)
     for (int i = tid; i < (NSLOT * KIMG + NSLOT * VIMG) / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
@@ -286,11 +293,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   }
 
   const int q_last = min(q0 + BQ, p.Nq) - 1;
-  const int kv_end = kv_limit(p, q_last);
+  const int kv_end = kv_limit(p, b, q_last);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   // first key index that is NOT visible to every query row of this wave (tiles below need no mask test)
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
-  const int full_vis_end = kv_limit(p, wave_q_first);
+  const int full_vis_end = kv_limit(p, b, wave_q_first);
 
   Stager<T, D, DMA ? 4 : BKV> sk, sv;
   if constexpr (DMA) {
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kb + 32 * u + acc_row(r, lh);
-          if (!(key < p.Nk && visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))) sc[u][r] = -INFINITY;
+          if (!(key < p.Nk && (prefix ? key < my_lim : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))) sc[u][r] = -INFINITY;
         }
     }
     float tmax = -INFINITY;
@@ -477,6 +484,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
   const int qrow = q0 + wave * 32 + li;
   const bool q_ok = qrow < p.Nq;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX;
+  const int my_lim = (prefix && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;
 
   if constexpr (C::DPAD != D) {   // padded columns feed the transposed K reads: keep them zero
     for (int i = tid; i < 4 * IMG / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
@@ -499,10 +508,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   const float dl = q_ok ? p.delta[stat] : 0.0f;
 
   const int q_last = min(q0 + BQ, p.Nq) - 1;
-  const int kv_end = kv_limit(p, q_last);
+  const int kv_end = kv_limit(p, b, q_last);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
-  const int full_vis_end = kv_limit(p, wave_q_first);
+  const int full_vis_end = kv_limit(p, b, wave_q_first);
 
   constexpr bool DMA = Img<T, D>::SWZ;
   Stager<T, D, DMA ? 4 : BKV> sk, sv;
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) {
           float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
           const int key = kb + 32 * u + acc_row(r, lh);
-          if (!(key < p.Nk && visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))) pv = 0.0f;
+          if (!(key < p.Nk && (prefix ? key < my_lim : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))) pv = 0.0f;
           sc[r] = pv * (dp[r] - dl);   // dS^T (without the softmax scale; folded into the final store)
         }
       }
@@ -614,6 +623,8 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
   const int krow = k0 + wave * 32 + li;
   const bool k_ok = krow < p.Nk;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX;
+  const int my_qf = (prefix && k_ok) ? p.qfirst[(int64_t)b * p.Nk + krow] : 0;
 
   if constexpr (C::DPAD != D) {
     for (int i = tid; i < 4 * IMG / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
@@ -632,10 +643,10 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
     }
   }
 
-  const int qs = (q_first(p, k0) / TQ) * TQ;                 // first query tile that can see key k0
+  const int qs = (q_first(p, b, k0) / TQ) * TQ;                 // first query tile that can see key k0
   const int ntiles = qs < p.Nq ? (p.Nq - qs + TQ - 1) / TQ : 0;
   // queries >= this index see every key of this wave's 32 keys
-  const int full_vis_q = q_first(p, min(k0 + wave * 32 + 31, p.Nk - 1));
+  const int full_vis_q = q_first(p, b, min(k0 + wave * 32 + 31, p.Nk - 1));
   const int64_t stat0 = ((int64_t)b * p.H + hd) * p.Nq;
 
   constexpr bool DMA = Img<T, D>::SWZ;          // bf16, D = 64: tiles arrive by LDS-DMA, no staging registers
@@ -742,7 +753,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
             const int r = 4 * g + j;
             float pv = __builtin_amdgcn_exp2f(sc[u][r] * c - l4[j]);
             const int q = qb + 32 * u + acc_row(r, lh);
-            if (!(k_ok && visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))) pv = 0.0f;
+            if (!(k_ok && (prefix ? q >= my_qf : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos)))) pv = 0.0f;
             sc[u][r] = pv;
             dp[u][r] = pv * (dp[u][r] - d4[j]);
           }
@@ -823,7 +834,7 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
                "%s: head_dim %lld unsupported (8/16/32/64, 128 for bf16)", name, (long long)D);
   FK_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B < 65536 && H < 65536 && Nq < (1LL << 30) && Nk < (1LL << 30) && B * H * ((Nq + 127) / 128) < (1LL << 31) && B * H * ((Nk + 127) / 128) < (1LL << 31),
                "%s: bad shape B=%lld H=%lld Nq=%lld Nk=%lld", name, (long long)B, (long long)H, (long long)Nq, (long long)Nk);
-  FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL,
+  FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL || mask_kind == FK_MASK_PREFIX,
                "%s: mask kind %d not supported", name, mask_kind);
   FK_CHECK_ARG(mask_kind != FK_MASK_BLOCK_CAUSAL || mask_c > 0, "%s: block-causal mask needs block size > 0", name);
   const int vec = dtype == FK_BF16 ? 8 : 4;
@@ -859,7 +870,7 @@ extern "C" {
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
                 int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
                 int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
-                float scale, int dtype, void* stream) {
+                const int32_t* limits, const int32_t* qfirst, float scale, int dtype, void* stream) {
   const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
   int rc = check_common("fk_attn_fwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
   if (rc) return rc;
@@ -870,6 +881,8 @@ int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
   a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
   a.B = (int)B; a.H = (int)H; a.Nq = (int)Nq; a.Nk = (int)Nk;
   a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
+  FK_CHECK_ARG(mask_kind != FK_MASK_PREFIX || (limits && qfirst), "fk_attn_fwd: prefix mask needs limits and qfirst");
+  a.limits = limits; a.qfirst = qfirst;
   FK_ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_fwd");
   return FK_OK;
@@ -878,8 +891,9 @@ int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
 int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                 void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                 int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
-                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, float scale,
-                const float* rope_table, int64_t rope_bs, int64_t rope_off, int dtype, void* stream) {
+                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
+                const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int dtype,
+                void* stream) {
   const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
   int rc = check_common("fk_attn_bwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
   if (rc) return rc;
@@ -894,6 +908,8 @@ int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
   a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
   FK_CHECK_ARG(!rope_table || (Nq == Nk && D % 4 == 0 && ((uintptr_t)rope_table & 15) == 0), "fk_attn_bwd: fused inverse RoPE needs self-attention (Nq == Nk)");
   a.rope_table = rope_table; a.rope_bs = rope_bs; a.rope_off = (int)rope_off;
+  FK_CHECK_ARG(mask_kind != FK_MASK_PREFIX || (limits && qfirst), "fk_attn_bwd: prefix mask needs limits and qfirst");
+  a.limits = limits; a.qfirst = qfirst;
   FK_ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_bwd");
   return FK_OK;

@@ -229,6 +229,57 @@ __global__ void embed_bwd_kernel(const int64_t* idx, const T* dout, int64_t ldo_
   }
 }
 
+// ---------------------------------------------------------------------------------------------- row gather / scatter (MAE)
+// dst[b, i, :] = src[b, idx[b, i], :] (gather)  or  dst[b, idx[b, i], :] = src[b, i, :] (scatter); W elements per row.
+// src_bs = 0 broadcasts one table over the batch (embedding lookup); TS -> TD converts on the fly.
+template <typename TS, typename TD>
+__global__ void gather_rows_kernel(const TS* src, int64_t src_bs, const int64_t* idx, int64_t idx_mod, TD* dst, int B, int n,
+                                   int W, int scatter, int64_t dst_bs) {
+  const int64_t total = (int64_t)B * n * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % W);
+    const int64_t r = i / W;
+    const int b = (int)(r / n), k = (int)(r % n);
+    int64_t j = idx[r];
+    if (idx_mod > 0) j %= idx_mod;
+    if (scatter) dst[(int64_t)b * dst_bs + j * W + c] = from_f32<TD>(to_f32<TS>(src[(int64_t)b * src_bs + (int64_t)k * W + c]));
+    else dst[(int64_t)b * dst_bs + (int64_t)k * W + c] = from_f32<TD>(to_f32<TS>(src[(int64_t)b * src_bs + j * W + c]));
+  }
+}
+// table[idx[b, i] % idx_mod, :] += src[b, i, :]   (fp32 atomics; gradient of a broadcast-table gather)
+template <typename TS>
+__global__ void scatter_add_rows_kernel(const TS* src, const int64_t* idx, int64_t idx_mod, float* table, int64_t rows, int W) {
+  const int64_t total = rows * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % W);
+    int64_t j = idx[i / W];
+    if (idx_mod > 0) j %= idx_mod;
+    atomicAdd(table + j * W + c, to_f32<TS>(src[i]));
+  }
+}
+// prefix-mask tables from sorted per-token block ids: limits[b, i] = #keys j with kid[b, j] / C <= qid[b, i] / C,
+// qfirst[b, j] = first query i with qid[b, i] / C >= kid[b, j] / C   (ids ascending within a sample)
+__global__ void prefix_mask_kernel(const int64_t* qid, const int64_t* kid, int C, int* limits, int* qfirst, int B, int nq, int nk) {
+  const int64_t total = (int64_t)B * (nq + nk);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(t / (nq + nk)), r = (int)(t % (nq + nk));
+    const int64_t* q = qid + (int64_t)b * nq;
+    const int64_t* k = kid + (int64_t)b * nk;
+    if (r < nq) {                       // upper bound over key blocks
+      const int64_t blk = q[r] / C;
+      int lo = 0, hi = nk;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (k[mid] / C <= blk) lo = mid + 1; else hi = mid; }
+      limits[(int64_t)b * nq + r] = lo;
+    } else {                            // lower bound over query blocks
+      const int j = r - nq;
+      const int64_t blk = k[j] / C;
+      int lo = 0, hi = nq;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] / C < blk) lo = mid + 1; else hi = mid; }
+      qfirst[(int64_t)b * nk + j] = lo;
+    }
+  }
+}
+
 }  // namespace
 
 #define FK_DT_CHECK(name) FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, name ": bad dtype %d", dtype)
@@ -377,6 +428,40 @@ int fk_gpt_embed_bwd_wte(const int64_t* idx, const void* dout, float* dwte, int6
   if (dtype == FK_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, idx, (const bf16_t*)dout, t_ctx + t_words, (int)t_ctx, (int)t_words, dwte, (int)B, (int)dim, (int)vocab);
   else hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, idx, (const float*)dout, t_ctx + t_words, (int)t_ctx, (int)t_words, dwte, (int)B, (int)dim, (int)vocab);
   FK_CHECK_LAUNCH("fk_gpt_embed_bwd_wte");
+  return FK_OK;
+}
+
+int fk_gather_rows(const void* src, int64_t src_bs, int src_dtype, const int64_t* idx, int64_t idx_mod, void* dst, int64_t dst_bs,
+                   int dst_dtype, int64_t B, int64_t n, int64_t W, int scatter, void* stream) {
+  FK_CHECK_ARG((src_dtype == FK_F32 || src_dtype == FK_BF16) && (dst_dtype == FK_F32 || dst_dtype == FK_BF16), "fk_gather_rows: bad dtype");
+  FK_CHECK_ARG(src && idx && dst && B > 0 && n > 0 && W > 0 && B * n < (1LL << 31) && W < (1LL << 31), "fk_gather_rows: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(grid_for(B * n * W, 16384)), b(TPB);
+#define FK_GR(TS, TD) hipLaunchKernelGGL((gather_rows_kernel<TS, TD>), g, b, 0, s, (const TS*)src, src_bs, idx, idx_mod, (TD*)dst, (int)B, (int)n, (int)W, scatter, dst_bs)
+  if (src_dtype == FK_F32 && dst_dtype == FK_F32) FK_GR(float, float);
+  else if (src_dtype == FK_F32) FK_GR(float, bf16_t);
+  else if (dst_dtype == FK_F32) FK_GR(bf16_t, float);
+  else FK_GR(bf16_t, bf16_t);
+#undef FK_GR
+  FK_CHECK_LAUNCH("fk_gather_rows");
+  return FK_OK;
+}
+int fk_scatter_add_rows(const void* src, int src_dtype, const int64_t* idx, int64_t idx_mod, float* table, int64_t rows, int64_t W,
+                        void* stream) {
+  FK_CHECK_ARG(src_dtype == FK_F32 || src_dtype == FK_BF16, "fk_scatter_add_rows: bad dtype");
+  FK_CHECK_ARG(src && idx && table && rows > 0 && W > 0, "fk_scatter_add_rows: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (src_dtype == FK_BF16) hipLaunchKernelGGL(scatter_add_rows_kernel<bf16_t>, dim3(grid_for(rows * W, 16384)), dim3(TPB), 0, s, (const bf16_t*)src, idx, idx_mod, table, rows, (int)W);
+  else hipLaunchKernelGGL(scatter_add_rows_kernel<float>, dim3(grid_for(rows * W, 16384)), dim3(TPB), 0, s, (const float*)src, idx, idx_mod, table, rows, (int)W);
+  FK_CHECK_LAUNCH("fk_scatter_add_rows");
+  return FK_OK;
+}
+int fk_prefix_mask(const int64_t* q_ids, const int64_t* k_ids, int64_t block, int32_t* limits, int32_t* qfirst, int64_t B,
+                   int64_t nq, int64_t nk, void* stream) {
+  FK_CHECK_ARG(q_ids && k_ids && limits && qfirst && block > 0 && B > 0 && nq > 0 && nk > 0, "fk_prefix_mask: bad arguments");
+  hipLaunchKernelGGL(prefix_mask_kernel, dim3(grid_for(B * (nq + nk), 4096)), dim3(TPB), 0, (hipStream_t)stream, q_ids, k_ids, (int)block,
+                     limits, qfirst, (int)B, (int)nq, (int)nk);
+  FK_CHECK_LAUNCH("fk_prefix_mask");
   return FK_OK;
 }
 

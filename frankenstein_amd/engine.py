@@ -498,3 +498,79 @@ def l1_loss(pred: Tensor, target: Tensor) -> Tensor:
 
 def mse_loss(pred: Tensor, target: Tensor) -> Tensor:
     return L1Loss.apply(pred, target, True)
+
+
+# --------------------------------------------------------------------------------------------- MAE pieces
+class GatherRows(torch.autograd.Function):
+    """out[b, i, :] = src[b, idx[b, i], :]  (models/brainformer.py:441,468); idx rows are unique per sample."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        ctx.n_src = src.shape[1]
+        ctx.save_for_backward(idx)
+        return K.gather_rows(src.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        d = torch.zeros((dy.shape[0], ctx.n_src, dy.shape[2]), dtype=dy.dtype, device=dy.device)
+        K.scatter_rows_(d, idx, dy)
+        return d, None
+
+
+class MaskedPatchEmbed(torch.autograd.Function):
+    """tokens = emb(patches[b, unmasked]) + spatial_pos_embedding[b, unmasked]  (models/brainformer.py:429-444)."""
+
+    @staticmethod
+    def forward(ctx, tok_all, emb_w, emb_b, space, unmasked, P):
+        B, N, kp = tok_all.shape
+        Cn, d = space.shape[1], space.shape[2]
+        tok_u = K.gather_rows(tok_all, unmasked)                                   # [B, n, kp]
+        sp = K.gather_rows(shadow([space.view(Cn, d)]), unmasked, idx_mod=Cn)     # spatial rows repeat every Cn tokens
+        n = unmasked.shape[1]
+        h = K.gemm_nt(tok_u.view(B * n, kp), shadow([emb_w], pad_k=kp), bias=shadow([emb_b]), residual=sp.view(B * n, d))
+        ctx.dims = (B, n, Cn, d, P)
+        ctx.save_for_backward(tok_u, unmasked)
+        return h.view(B, n, d)
+
+    @staticmethod
+    def backward(ctx, dh):
+        tok_u, unmasked = ctx.saved_tensors
+        B, n, Cn, d, P = ctx.dims
+        dh2 = dh.contiguous().view(B * n, d)
+        dw = K.gemm_tn(dh2, tok_u.view(B * n, -1))[:, :P].contiguous()
+        db = K.colsum(dh2)
+        dspace = torch.zeros((Cn, d), dtype=torch.float32, device=dh.device)
+        K.scatter_add_rows_(dspace, unmasked, dh2, idx_mod=Cn)
+        return None, dw, db, dspace.view(1, Cn, d), None, None
+
+
+class AssembleDecoder(torch.autograd.Function):
+    """dec[b, unmasked] = tokens, dec[b, masked] = mask_token, + decoder_pos_emb[cat(unmasked, masked)] added in
+    CONCATENATION order (the reference's quirk, models/brainformer.py:455-460)."""
+
+    @staticmethod
+    def forward(ctx, tokens, mask_token, pos_table, unmasked, masked):
+        B, n, dd = tokens.shape
+        N = n + masked.shape[1]
+        row = shadow([mask_token.view(1, dd)])
+        dec = torch.empty((B, N, dd), dtype=tokens.dtype, device=tokens.device)
+        K.copy2d(row.expand(B * N, dd), dec.view(B * N, dd))                       # every row = mask_token ...
+        K.scatter_rows_(dec, unmasked, tokens.contiguous())                        # ... then the visible tokens
+        order = torch.cat([unmasked, masked], 1).contiguous()
+        pos = K.gather_rows(pos_table.detach(), order, out_dtype=tokens.dtype)     # [B, N, dd] in concatenation order
+        ctx.save_for_backward(unmasked, masked, order)
+        ctx.tshape = pos_table.shape
+        return K.add(dec, pos)
+
+    @staticmethod
+    def backward(ctx, dy):
+        unmasked, masked, order = ctx.saved_tensors
+        dy = dy.contiguous()
+        dd = dy.shape[2]
+        dtok = K.gather_rows(dy, unmasked)
+        dmask = K.colsum(K.gather_rows(dy, masked).view(-1, dd))
+        dpos = torch.zeros(ctx.tshape, dtype=torch.float32, device=dy.device)
+        K.scatter_add_rows_(dpos, order, dy)
+        return dtok, dmask, dpos, None, None

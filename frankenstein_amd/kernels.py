@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_NONE, NORM_LAYER, NORM_RMS, call, lib
+from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_NONE, MASK_PREFIX, NORM_LAYER, NORM_RMS, call, lib
 
 Tensor = torch.Tensor
 
@@ -169,13 +169,27 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
 class Mask:
     """Analytic attention mask: kind in {none, causal, block_causal(C)} with position offsets
     (the reference slices its [N,N] buffer as mask[..., -t_q:, -t_k:], models/brainformer.py:160-162)."""
-    __slots__ = ("kind", "c", "q_off", "k_off")
+    __slots__ = ("kind", "c", "q_off", "k_off", "limits", "qfirst")
 
-    def __init__(self, kind: int = MASK_NONE, c: int = 0, q_off: int = 0, k_off: int = 0):
-        self.kind, self.c, self.q_off, self.k_off = kind, c, q_off, k_off
+    def __init__(self, kind: int = MASK_NONE, c: int = 0, q_off: int = 0, k_off: int = 0, limits=None, qfirst=None):
+        self.kind, self.c, self.q_off, self.k_off, self.limits, self.qfirst = kind, c, q_off, k_off, limits, qfirst
 
     def sliced(self, n_full_q: int, n_full_k: int, t_q: int, t_k: int) -> "Mask":
-        return Mask(self.kind, self.c, self.q_off + n_full_q - t_q, self.k_off + n_full_k - t_k)
+        assert self.kind != MASK_PREFIX or (n_full_q == t_q and n_full_k == t_k), "prefix masks cannot be sliced"
+        return Mask(self.kind, self.c, self.q_off + n_full_q - t_q, self.k_off + n_full_k - t_k, self.limits, self.qfirst)
+
+    @staticmethod
+    def from_token_ids(q_ids: Tensor, k_ids: Tensor, block: int) -> "Mask":
+        """Sub-mask of the block-causal mask at (ascending) token indices: visible(i, j) = k_ids[j] // block <= q_ids[i] // block
+        (MAE.get_sub_att_matrix, models/brainformer.py:392-413), as prefix tables instead of a [B,1,n,n] tensor."""
+        assert q_ids.dtype == torch.int64 and k_ids.dtype == torch.int64 and q_ids.dim() == 2 and k_ids.dim() == 2
+        B, nq = q_ids.shape
+        nk = k_ids.shape[1]
+        limits = torch.empty((B, nq), dtype=torch.int32, device=q_ids.device)
+        qfirst = torch.empty((B, nk), dtype=torch.int32, device=q_ids.device)
+        call("fk_prefix_mask", q_ids.contiguous().data_ptr(), k_ids.contiguous().data_ptr(), block, limits.data_ptr(),
+             qfirst.data_ptr(), B, nq, nk, _stream())
+        return Mask(MASK_PREFIX, block, 0, 0, limits, qfirst)
 
 
 NO_MASK = Mask()
@@ -199,7 +213,8 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optio
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
     with _timed(f"attn_fwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
       call("fk_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
-           qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, sc, fk_dtype(q), _stream())
+           qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst),
+           sc, fk_dtype(q), _stream())
     return out, lse
 
 
@@ -217,7 +232,7 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     with _timed(f"attn_bwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
       call("fk_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
-           mask.kind, mask.c, mask.q_off, mask.k_off, sc, _ptr(rope_table),
+           mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst), sc, _ptr(rope_table),
            0 if rope_table is None or rope_table.dim() == 3 else rope_table.stride(0), rope_off, fk_dtype(q), _stream())
 
 
@@ -336,6 +351,41 @@ def add(a: Tensor, b: Tensor) -> Tensor:
     y = torch.empty_like(a)
     call("fk_add", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), fk_dtype(a), _stream())
     return y
+
+
+def gather_rows(src: Tensor, idx: Tensor, out_dtype: Optional[torch.dtype] = None, idx_mod: int = 0) -> Tensor:
+    """out[b, i, :] = src[b, idx[b,i] (% idx_mod), :]; src [B, N, W] or a shared table [N, W]; idx int64 [B, n]."""
+    assert idx.dtype == torch.int64 and idx.dim() == 2 and idx.is_contiguous() and src.is_contiguous()
+    B, n = idx.shape
+    W = src.shape[-1]
+    sbs = src.shape[-2] * W if src.dim() == 3 else 0
+    assert src.dim() == 2 or src.shape[0] == B
+    odt = out_dtype or src.dtype
+    out = torch.empty((B, n, W), dtype=odt, device=src.device)
+    call("fk_gather_rows", src.data_ptr(), sbs, fk_dtype(src), idx.data_ptr(), idx_mod, out.data_ptr(), n * W, fk_dtype(odt),
+         B, n, W, 0, _stream())
+    return out
+
+
+def scatter_rows_(dst: Tensor, idx: Tensor, src: Tensor) -> Tensor:
+    """dst[b, idx[b,i], :] = src[b, i, :]   (dst [B, N, W] contiguous, updated in place)."""
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and src.is_contiguous() and dst.is_contiguous()
+    B, n = idx.shape
+    W = src.shape[-1]
+    assert src.shape == (B, n, W) and dst.dim() == 3 and dst.shape[0] == B and dst.shape[2] == W
+    call("fk_gather_rows", src.data_ptr(), n * W, fk_dtype(src), idx.data_ptr(), 0, dst.data_ptr(), dst.shape[1] * W,
+         fk_dtype(dst), B, n, W, 1, _stream())
+    return dst
+
+
+def scatter_add_rows_(table: Tensor, idx: Tensor, src: Tensor, idx_mod: int = 0) -> Tensor:
+    """table[idx[r] (% idx_mod), :] += src[r, :]  (fp32 table; atomics)."""
+    assert table.dtype == torch.float32 and table.is_contiguous() and src.is_contiguous() and idx.is_contiguous()
+    W = table.shape[-1]
+    rows = idx.numel()
+    assert src.numel() == rows * W
+    call("fk_scatter_add_rows", src.data_ptr(), fk_dtype(src), idx.data_ptr(), idx_mod, table.data_ptr(), rows, W, _stream())
+    return table
 
 
 def copy2d(src: Tensor, dst: Tensor) -> Tensor:

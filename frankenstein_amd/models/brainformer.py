@@ -359,6 +359,81 @@ class Encoder(nn.Module):
         return self.transformer.ln_f(h)
 
 
+class MAE(nn.Module):
+    """Masked auto-encoder pretraining (models/brainformer.py:354-486): encode a random 1 - masking_ratio subset of the
+    patch tokens (per-sample RoPE rows and the gathered block-causal sub-mask, evaluated as prefix tables), decode all
+    tokens with mask tokens + positional embedding, MSE on the masked patches.  ``indices=(masked, unmasked)`` lets a
+    caller (parity tests) supply the random index sets; otherwise they are drawn like the reference does."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.decoder_dim = config.decoder_dim
+        self.encoder = Encoder(config)
+        self.decoder = nn.ModuleDict(dict(
+            emb=nn.Identity(),
+            h=nn.ModuleList([Block(config) for _ in range(config.n_dec_layers)]),
+        ))
+        self.mask_token = nn.Parameter(torch.randn(config.dim))
+        self.decoder_pos_emb = nn.Embedding(self.encoder.block_size, config.decoder_dim)
+        self.to_signals = Linear(config.decoder_dim, config.patch_size)
+        print("MAE: number of parameters: %.2fM" % (self.get_num_params() / 1e6))
+
+    def get_num_params(self, non_embedding=True):
+        return sum(p.numel() for p in self.parameters())
+
+    def get_masking_indices(self, masking_ratio, x):
+        b, n_tokens, _ = x.shape
+        num_masked = int(masking_ratio * n_tokens)
+        rand_indices = torch.rand(b, n_tokens, device=x.device).argsort(dim=-1)
+        masked, unmasked = rand_indices[:, :num_masked], rand_indices[:, num_masked:]
+        return torch.sort(masked, dim=1)[0], torch.sort(unmasked, dim=1)[0]
+
+    def to_signal_shape(self, tok):
+        """'b (t c) p -> b (t p) c'  (host-side view math on the small return_preds outputs)."""
+        B, N, P = tok.shape
+        Cn = self.config.n_electrodes
+        return tok.view(B, N // Cn, Cn, P).permute(0, 1, 3, 2).reshape(B, (N // Cn) * P, Cn)
+
+    def forward(self, x, targets=None, date_info=None, masking_ratio=0.75, return_preds=False, indices=None):
+        cfg, enc = self.config, self.encoder
+        B, T, Cn = x.shape
+        P = cfg.patch_size
+        kp = (P + 31) // 32 * 32
+        xin = x if x.dtype == torch.float32 else x.float()
+        tok_all = K.patchify(xin.contiguous(), P, kp, E.compute_dtype()).view(B, (T // P) * Cn, kp)
+        n_tokens = tok_all.shape[1]
+        if indices is None:
+            masked, unmasked = self.get_masking_indices(masking_ratio, tok_all)
+        else:
+            masked, unmasked = indices
+        masked, unmasked = masked.contiguous(), unmasked.contiguous()
+        # per-sample rope rows and the sub-mask of the block-causal mask at the kept tokens
+        table = torch.view_as_real(enc.rope_cache).reshape(enc.block_size, -1)
+        rope = K.gather_rows(table.contiguous(), unmasked).view(B, unmasked.shape[1], -1, 2)
+        mask = Mask.from_token_ids(unmasked, unmasked, enc.n_electrodes)
+        tokens = E.MaskedPatchEmbed.apply(tok_all, enc.transformer.emb.weight, enc.transformer.emb.bias,
+                                          enc.space_embedding, unmasked, P)
+        for block in enc.transformer.h:
+            tokens = block(tokens, attn_mask=mask, rope=rope)
+        tokens = enc.transformer.ln_f(tokens)
+        dec = E.AssembleDecoder.apply(self.decoder.emb(tokens), self.mask_token, self.decoder_pos_emb.weight, unmasked, masked)
+        for block in self.decoder.h:
+            dec = block(dec)
+        pred = self.to_signals(E.GatherRows.apply(dec, masked))                    # [B, n_masked, P]
+        tok_p = tok_all if kp == P else K.patchify(xin.contiguous(), P, P, E.compute_dtype()).view(B, n_tokens, P)
+        target = K.gather_rows(tok_p, masked)                                      # [B, n_masked, P] (data, no gradient)
+        loss = E.mse_loss(pred, target)
+        if return_preds:
+            with torch.no_grad():
+                rec = K.cast(tok_p, torch.float32)
+                K.scatter_rows_(rec, masked, pred.detach().float().contiguous())
+                bm = torch.zeros_like(rec)
+                K.scatter_rows_(bm, masked, torch.ones_like(pred, dtype=torch.float32))
+            return loss, self.to_signal_shape(rec), self.to_signal_shape(bm)
+        return (loss, None)
+
+
 class BrainFormer(nn.Module):
     config = Config
     head_name = 'to_motion'

@@ -31,7 +31,7 @@ extern "C" {
 #define FK_EUNSUPPORTED (-3)
 
 enum { FK_F32 = 0, FK_BF16 = 1 };
-enum { FK_MASK_NONE = 0, FK_MASK_CAUSAL = 1, FK_MASK_BLOCK_CAUSAL = 2 };
+enum { FK_MASK_NONE = 0, FK_MASK_CAUSAL = 1, FK_MASK_BLOCK_CAUSAL = 2, FK_MASK_PREFIX = 3 };
 enum { FK_NORM_LAYER = 0, FK_NORM_RMS = 1 };
 enum { FK_ACT_SWIGLU = 0, FK_ACT_GELU = 1 };
 
@@ -75,18 +75,20 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
  * Q,K,V,O are [B, N, H, D] views: element (b,n,h,d) at base + b*bs + n*rs + h*D + d.  LSE [B,H,Nq] fp32.
  * mask: NONE | CAUSAL (k + k_off <= q + q_off) | BLOCK_CAUSAL ((k + k_off)/mask_c <= (q + q_off)/mask_c), the
  * analytic form of build_advanced_causal_mask (models/brainformer.py:93-111) incl. the [-t_q:, -t_k:] slice (:160-162).
- * Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
+ * PREFIX (per-sample masks of sorted token subsets, MAE's get_sub_att_matrix models/brainformer.py:392-413):
+ * visible(q,k) = k < limits[b,q] <=> q >= qfirst[b,k], int32 tables from fk_prefix_mask.  Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
  * Q/K/V's strides; delta_ws is [B,H,Nq] fp32 scratch.  rope_table != NULL (self-attention only) additionally applies the
  * inverse RoPE (rotation by -angle at position rope_off + index) to dQ and dK as they are stored = apply_rope's backward.                                                        */
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
                 int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
                 int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
-                float scale, int dtype, void* stream);
+                const int32_t* limits, const int32_t* qfirst, float scale, int dtype, void* stream);
 int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                 void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                 int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
-                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, float scale,
-                const float* rope_table, int64_t rope_bs, int64_t rope_off, int dtype, void* stream);
+                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
+                const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int dtype,
+                void* stream);
 
 /* ---- normalisation (nn.LayerNorm: models/brainformer.py:237,239,252,254,287,500; F.layer_norm models/gpt2_model.py:27;
  *      RMSNorm models/brainformer.py:221-232).  x,y [rows, dim] contiguous; gamma/beta fp32 (beta may be NULL);
@@ -128,6 +130,18 @@ int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
 /* y = a + b (same dtype) */
 int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
 
+/* ---- MAE gather / scatter (models/brainformer.py:429-457,468,472): rows of W elements.
+ * gather : dst[b, i, :] = src[b, idx[b,i] (% idx_mod), :]     (src_bs = 0 broadcasts one table: embedding / pos-emb lookup)
+ * scatter: dst[b, idx[b,i], :] = src[b, i, :]                 dtypes converted on the fly; batch strides in elements.
+ * fk_scatter_add_rows: table[idx[r] (% idx_mod), :] += src[r, :] (fp32 atomics; gradient of a broadcast gather).
+ * fk_prefix_mask: limits[b,i] = #{j : kid[b,j]/block <= qid[b,i]/block}, qfirst[b,j] = min{i : qid[b,i]/block >= kid[b,j]/block}
+ * for ascending per-sample token ids = the analytic form of the gathered block-causal sub-mask.                        */
+int fk_gather_rows(const void* src, int64_t src_bs, int src_dtype, const int64_t* idx, int64_t idx_mod, void* dst, int64_t dst_bs,
+                   int dst_dtype, int64_t B, int64_t n, int64_t W, int scatter, void* stream);
+int fk_scatter_add_rows(const void* src, int src_dtype, const int64_t* idx, int64_t idx_mod, float* table, int64_t rows, int64_t W,
+                        void* stream);
+int fk_prefix_mask(const int64_t* q_ids, const int64_t* k_ids, int64_t block, int32_t* limits, int32_t* qfirst, int64_t B,
+                   int64_t nq, int64_t nk, void* stream);
 /* 2-D strided copy (same dtype): dst[r*ldd + c] = src[r*lds + c]. */
 int fk_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype, void* stream);
 

@@ -335,3 +335,44 @@ def gpt_shapes(cfg, p: str = "") -> Dict[str, tuple]:
             s.update({q + "ln_1.bias": (d,), q + "ln_2.bias": (d,), q + "attn.c_attn.bias": (3 * d,),
                       q + "attn.c_proj.bias": (d,), q + "mlp.c_fc.bias": (4 * d,), q + "mlp.c_proj.bias": (d,)})
     return s
+
+
+# --------------------------------------------------------------------------- MAE
+def mae_shapes(cfg, p: str = "") -> Dict[str, tuple]:
+    """State-dict keys of brainformer.MAE (models/brainformer.py:354-374), minus the attn_mask buffer."""
+    s = encoder_shapes(cfg, p + "encoder.")
+    d, hd, H = cfg.dim, cfg.head_dim * cfg.n_heads, cfg.hidden_dim
+    for i in range(cfg.n_dec_layers):
+        s.update(block_shapes(f"{p}decoder.h.{i}.", d, hd, H))
+    n_tok = (cfg.window_size // cfg.patch_size) * cfg.n_electrodes
+    s.update({p + "mask_token": (cfg.dim,), p + "decoder_pos_emb.weight": (n_tok, cfg.decoder_dim),
+              p + "to_signals.weight": (cfg.patch_size, cfg.decoder_dim), p + "to_signals.bias": (cfg.patch_size,)})
+    return s
+
+
+def mae_forward(sd, x: Tensor, cfg, masked: Tensor, unmasked: Tensor, p: str = ""):
+    """models/brainformer.py:415-473 with the random index sets given (they are inputs of the parity fixture).
+    Returns (mse loss, predictions for the masked patches [B, n_masked, patch])."""
+    B = x.shape[0]
+    n_t = cfg.window_size // cfg.patch_size
+    n_tok = n_t * cfg.n_electrodes
+    tok = to_patches(x, cfg.patch_size)                                   # [B, N, P]
+    br = torch.arange(B)[:, None]
+    space = sd[p + "encoder.space_embedding"].repeat(1, n_t, 1).expand(B, -1, -1)[br, unmasked]
+    ang = rope_angles(cfg.head_dim, n_tok, cfg.rope_theta).expand(B, -1, -1)[br, unmasked]      # per-sample rows (:430-434)
+    full = block_causal_mask(n_tok, cfg.n_electrodes)
+    sub = full.expand(B, -1, -1)[torch.arange(B)[:, None, None], unmasked[..., None], unmasked[:, None, :]][:, None]
+    h = linear(tok[br, unmasked], sd[p + "encoder.transformer.emb.weight"], sd[p + "encoder.transformer.emb.bias"]) + space
+    for i in range(cfg.n_layers):
+        h = block(sd, f"{p}encoder.transformer.h.{i}.", h, cfg, sub, ang)
+    h = layer_norm(h, sd[p + "encoder.transformer.ln_f.weight"], sd[p + "encoder.transformer.ln_f.bias"])
+    dec = torch.zeros(B, n_tok, cfg.decoder_dim)
+    dec = dec.index_put((br, unmasked), h)
+    dec = dec.index_put((br, masked), sd[p + "mask_token"].expand(B, masked.shape[1], -1))
+    # quirk kept from the reference (:459-460): positional rows are added in CONCATENATION order, not scattered
+    dec = dec + sd[p + "decoder_pos_emb.weight"][torch.cat([unmasked, masked], 1)]
+    for i in range(cfg.n_dec_layers):
+        dec = block(sd, f"{p}decoder.h.{i}.", dec, cfg, None, None)
+    pred = linear(dec[br, masked], sd[p + "to_signals.weight"], sd[p + "to_signals.bias"])
+    loss = ((pred - tok[br, masked]) ** 2).mean()
+    return loss, pred

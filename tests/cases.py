@@ -83,3 +83,15 @@ def summarize_rows(named):
         names.append(k)
         rows.append(np.concatenate([[a.sum(), np.abs(a).sum()], head]))
     return names, np.array(rows)
+
+
+def mae_small():
+    cfg = R.mae_config(window_size=32, n_electrodes=16, patch_size=4, dim=64, n_layers=2, head_dim=16, hidden_dim=128,
+                       n_heads=4, n_kv_heads=4, n_dec_layers=2, decoder_dim=64)
+    return cfg, t(synth.make_inputs(3, 32, 16))
+
+
+def unpatch(tok, C, P):
+    """'b (t c) p -> b (t p) c' (models/brainformer.py:372)"""
+    B, N, _ = tok.shape
+    return tok.view(B, N // C, C, P).permute(0, 1, 3, 2).reshape(B, (N // C) * P, C)

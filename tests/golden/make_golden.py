@@ -258,6 +258,21 @@ def main():
     save("cfg2_b1", loss=np.array(float(loss)), pred=pred.detach().numpy(),
          enc_rows=ctx[0, [0, 1, 255, 256, 3071, 6143]].numpy(), grad_names=gn, grad_rows=gr)
 
+    # ---- mae_small: brainformer.MAE (models/brainformer.py:354-486); the random index sets are recorded as inputs
+    enc = bf.MAEConfig(window_size=32, n_electrodes=16, patch_size=4, dim=64, n_layers=2, head_dim=16, hidden_dim=128,
+                       n_heads=4, n_kv_heads=4, n_dec_layers=2, decoder_dim=64)
+    mae = bf.MAE(enc).float()
+    load_synth(mae)
+    x = torch.from_numpy(synth.make_inputs(3, 32, 16))
+    torch.manual_seed(123)
+    masked, unmasked = mae.get_masking_indices(0.75, mae.encoder.to_patches(x))
+    torch.manual_seed(123)
+    loss, recon, bmask = mae(x, masking_ratio=0.75, return_preds=True)
+    loss.backward()
+    save("mae_small", loss=np.array(float(loss)), masked=masked.numpy(), unmasked=unmasked.numpy(),
+         recon=recon.detach().numpy(), binary_mask=bmask.detach().numpy(),
+         **{"grad/" + k: v.numpy() for k, v in grads_of(mae).items()})
+
 
 if __name__ == "__main__":
     main()

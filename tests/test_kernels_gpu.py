@@ -411,3 +411,46 @@ def test_fused_rope_projection_and_backward(K, dtype):
     K.rope_(d1, 2 * H, D, dev(table), 64 - T, conj=True)
     K.attn_bwd(qv, kv, vv, o, do, lse, *views(d2), K.Mask(1), rope_table=dev(table), rope_off=64 - T)
     close(d2, d1.float().cpu(), dtype, atol32=1e-6, atol16=3e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gather_scatter_rows(K, dtype):
+    B, N, n, W = 3, 40, 11, 24
+    src = rnd(B, N, W, seed=1)
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(i))[:n].sort()[0] for i in range(B)])
+    g = K.gather_rows(dev(src, dtype), dev(idx))
+    want = q(src, dtype)[torch.arange(B)[:, None], idx]
+    assert torch.equal(g.float().cpu(), want)
+    d = torch.zeros(B, N, W, device="cuda", dtype=dtype)
+    K.scatter_rows_(d, dev(idx), g)
+    ref = torch.zeros(B, N, W).index_put((torch.arange(B)[:, None], idx), want)
+    assert torch.equal(d.float().cpu(), ref)
+    table = rnd(7, W, seed=2)                                   # shared fp32 table, index modulo, cast on the fly
+    t = K.gather_rows(dev(table), dev(idx), out_dtype=dtype, idx_mod=7)
+    assert torch.equal(t.float().cpu(), q(table[idx % 7], dtype))
+    acc = torch.zeros(7, W, device="cuda")
+    K.scatter_add_rows_(acc, dev(idx), g, idx_mod=7)
+    ref = torch.zeros(7, W).index_put(((idx % 7).reshape(-1),), want.reshape(-1, W), accumulate=True)
+    close(acc, ref, torch.float32, atol32=1e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_prefix_mask_from_token_ids(K, dtype):
+    """MAE sub-mask: mask[i, j] = (ids[j] // C) <= (ids[i] // C) at gathered (sorted) token ids, models/brainformer.py:392-413."""
+    B, H, N, n, D, Cb = 2, 2, 512, 200, 32, 16
+    ids = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(10 + i))[:n].sort()[0] for i in range(B)])
+    m = K.Mask.from_token_ids(dev(ids), dev(ids), Cb)
+    dense = (ids[:, None, :] // Cb) <= (ids[:, :, None] // Cb)                 # [B, n, n]
+    assert torch.equal(m.limits.cpu().long(), dense.sum(-1))
+    qv, kv, vv, do = (rnd(B, n, H, D, seed=s) for s in (1, 2, 3, 4))
+    qd, kd, vd = dev(qv, dtype), dev(kv, dtype), dev(vv, dtype)
+    o, lse = K.attn_fwd(qd, kd, vd, m)
+    qr, kr, vr = (q(t_, dtype).requires_grad_(True) for t_ in (qv, kv, vv))
+    oref = ref_attn(qr, kr, vr, dense[:, None])
+    close(o, oref, dtype, atol32=2e-5, atol16=2e-2)
+    oref.backward(q(do, dtype))
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    K.attn_bwd(qd, kd, vd, o, dev(do, dtype), lse, dq, dk, dv, m)
+    close(dq, qr.grad, dtype, atol32=5e-5, atol16=4e-2)
+    close(dk, kr.grad, dtype, atol32=5e-5, atol16=4e-2)
+    close(dv, vr.grad, dtype, atol32=5e-5, atol16=4e-2)

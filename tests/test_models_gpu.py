@@ -274,3 +274,25 @@ def test_run_train_model_end_to_end(tmp_path):
         assert torch.equal(v.cpu(), saved[k]), k
     x = torch.randn(2, 32, 16, generator=torch.Generator().manual_seed(5)).cuda()
     assert torch.isfinite(m2(x)[1]).all()       # (m itself took one more step after the last checkpoint, :182-185)
+
+
+def test_mae_small_fp32(golden):
+    """brainformer.MAE with the reference's random index sets as inputs (models/brainformer.py:415-486)."""
+    from frankenstein_amd.models import brainformer as bf
+    z = golden("mae_small")
+    cfgo, x = C.mae_small()
+    cfg = bf.MAEConfig(window_size=32, n_electrodes=16, patch_size=4, dim=64, n_layers=2, head_dim=16, hidden_dim=128,
+                       n_heads=4, n_kv_heads=4, n_dec_layers=2, decoder_dim=64)
+    m = load_synth(bf.MAE(cfg))
+    idx = (torch.from_numpy(z["masked"]).cuda(), torch.from_numpy(z["unmasked"]).cuda())
+    loss, recon, bmask = m(x.cuda(), masking_ratio=0.75, return_preds=True, indices=idx)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    np.testing.assert_allclose(recon.cpu().numpy(), z["recon"], atol=1e-4)
+    np.testing.assert_array_equal(bmask.cpu().numpy(), z["binary_mask"])
+    loss.backward()
+    check_full_grads(m, z)
+    # index sets drawn internally (training use): finite loss, right shapes
+    l2, none = m(x.cuda())
+    assert none is None and torch.isfinite(l2)
+    ma, un = m.get_masking_indices(0.75, torch.zeros(3, 128, 4, device="cuda"))
+    assert ma.shape == (3, 96) and un.shape == (3, 32) and bool((ma[:, 1:] > ma[:, :-1]).all())

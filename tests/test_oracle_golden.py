@@ -148,3 +148,20 @@ def test_cfg2_b1(golden):
     want = {str(n): r for n, r in zip(z["grad_names"], z["grad_rows"])}
     for n, r in zip(names, rows):
         np.testing.assert_allclose(r, want[n], rtol=2e-3, atol=2e-4, err_msg=n)
+
+
+def test_mae_small(golden):
+    z = golden("mae_small")
+    cfg, x = C.mae_small()
+    sd = leafify(C.state(R.mae_shapes(cfg)))
+    masked, unmasked = torch.from_numpy(z["masked"]), torch.from_numpy(z["unmasked"])
+    loss, pred = R.mae_forward(sd, x, cfg, masked, unmasked)
+    assert abs(float(loss) - float(z["loss"])) < 2e-6
+    # reconstruction = predictions at masked tokens, original patches elsewhere (models/brainformer.py:475-485)
+    tok = R.to_patches(x, cfg.patch_size)
+    br = torch.arange(3)[:, None]
+    rec = tok.clone().index_put((br, masked), pred.detach())
+    np.testing.assert_allclose(C.unpatch(rec, 16, 4).numpy(), z["recon"], atol=2e-5)
+    bm = torch.zeros_like(tok).index_put((br, masked), torch.ones(3, masked.shape[1], 4))
+    np.testing.assert_array_equal(C.unpatch(bm, 16, 4).numpy(), z["binary_mask"])
+    check_grads(grads(loss, sd), z)
