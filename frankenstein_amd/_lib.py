@@ -11,7 +11,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libfranken_hip.so"
 
 FK_F32, FK_BF16 = 0, 1
-MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL, MASK_PREFIX = 0, 1, 2, 3
+MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL, MASK_PREFIX, MASK_KEYPAD = 0, 1, 2, 3, 4
 NORM_LAYER, NORM_RMS = 0, 1
 
 _p, _i64, _int, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -50,8 +50,8 @@ SIGNATURES = {
     "fk_gpt_embed_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gpt_embed_bwd_wte": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_loss_workspace_bytes": (_sz, [_i64]),
-    "fk_l1_loss_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p, _sz, _p]),
-    "fk_l1_loss_bwd": (_int, [_p, _p, _p, _p, _i64, _int, _int, _p]),
+    "fk_l1_loss_fwd": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _int, _p, _sz, _p]),
+    "fk_l1_loss_bwd": (_int, [_p, _p, _p, _p, _i64, _int, _p, _i64, _p, _int, _p]),
     "fk_ce_workspace_bytes": (_sz, [_i64]),
     "fk_ce_loss_fwd": (_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p, _sz, _p]),
     "fk_ce_loss_bwd": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),

@@ -63,6 +63,7 @@ FK_DEV bool visible(int kind, int c, int qpos, int kpos) {
 // exclusive upper bound of key INDICES visible to query index q (monotone predicates only)
 FK_DEV int kv_limit(const AttnArgs& p, int b, int q) {
   if (p.mask_kind == FK_MASK_PREFIX) return min(p.Nk, p.limits[(int64_t)b * p.Nq + q]);
+  if (p.mask_kind == FK_MASK_KEYPAD) return 0;        // no structure: every tile takes the per-element path
   const int qpos = q + p.q_off;
   if (p.mask_kind == FK_MASK_CAUSAL) return min(p.Nk, max(0, qpos - p.k_off + 1));
   if (p.mask_kind == FK_MASK_BLOCK_CAUSAL) return min(p.Nk, max(0, (qpos / p.mask_c + 1) * p.mask_c - p.k_off));
@@ -71,6 +72,7 @@ FK_DEV int kv_limit(const AttnArgs& p, int b, int q) {
 // smallest query INDEX that can see key index k
 FK_DEV int q_first(const AttnArgs& p, int b, int k) {
   if (p.mask_kind == FK_MASK_PREFIX) return p.qfirst[(int64_t)b * p.Nk + k];
+  if (p.mask_kind == FK_MASK_KEYPAD) return 0x3fffffff;   // 'no query sees every key for free' -> always the predicate path
   const int kpos = k + p.k_off;
   if (p.mask_kind == FK_MASK_CAUSAL) return max(0, kpos - p.q_off);
   if (p.mask_kind == FK_MASK_BLOCK_CAUSAL) return max(0, (kpos / p.mask_c) * p.mask_c - p.q_off);
@@ -277,8 +279,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
   const int qrow = q0 + wave * 32 + li;
   const bool q_ok = qrow < p.Nq;
-  const bool prefix = p.mask_kind == FK_MASK_PREFIX;
-  const int my_lim = (prefix && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const int my_lim = ((prefix || keypad) && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;   // prefix length / query validity
 
   if constexpr (C::DPAD != D) {   // zero the padded columns of the K/V images once (never restaged)
     for (int i = tid; i < (NSLOT * KIMG + NSLOT * VIMG) / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   }
 
   const int q_last = min(q0 + BQ, p.Nq) - 1;
-  const int kv_end = kv_limit(p, b, q_last);
+  const int kv_end = p.mask_kind == FK_MASK_KEYPAD ? p.Nk : kv_limit(p, b, q_last);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   // first key index that is NOT visible to every query row of this wave (tiles below need no mask test)
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kb + 32 * u + acc_row(r, lh);
-          if (!(key < p.Nk && (prefix ? key < my_lim : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))) sc[u][r] = -INFINITY;
+          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))))) sc[u][r] = -INFINITY;
         }
     }
     float tmax = -INFINITY;
@@ -484,8 +486,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
   const int qrow = q0 + wave * 32 + li;
   const bool q_ok = qrow < p.Nq;
-  const bool prefix = p.mask_kind == FK_MASK_PREFIX;
-  const int my_lim = (prefix && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const int my_lim = ((prefix || keypad) && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;   // prefix length / query validity
 
   if constexpr (C::DPAD != D) {   // padded columns feed the transposed K reads: keep them zero
     for (int i = tid; i < 4 * IMG / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   const float dl = q_ok ? p.delta[stat] : 0.0f;
 
   const int q_last = min(q0 + BQ, p.Nq) - 1;
-  const int kv_end = kv_limit(p, b, q_last);
+  const int kv_end = p.mask_kind == FK_MASK_KEYPAD ? p.Nk : kv_limit(p, b, q_last);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
   const int full_vis_end = kv_limit(p, b, wave_q_first);
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) {
           float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
           const int key = kb + 32 * u + acc_row(r, lh);
-          if (!(key < p.Nk && (prefix ? key < my_lim : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))) pv = 0.0f;
+          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))))) pv = 0.0f;
           sc[r] = pv * (dp[r] - dl);   // dS^T (without the softmax scale; folded into the final store)
         }
       }
@@ -623,8 +625,8 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
   const int krow = k0 + wave * 32 + li;
   const bool k_ok = krow < p.Nk;
-  const bool prefix = p.mask_kind == FK_MASK_PREFIX;
-  const int my_qf = (prefix && k_ok) ? p.qfirst[(int64_t)b * p.Nk + krow] : 0;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const int my_qf = ((prefix || keypad) && k_ok) ? p.qfirst[(int64_t)b * p.Nk + krow] : 0;     // first query / key validity
 
   if constexpr (C::DPAD != D) {
     for (int i = tid; i < 4 * IMG / 4; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
     }
   }
 
-  const int qs = (q_first(p, b, k0) / TQ) * TQ;                 // first query tile that can see key k0
+  const int qs = p.mask_kind == FK_MASK_KEYPAD ? 0 : (q_first(p, b, k0) / TQ) * TQ;                 // first query tile that can see key k0
   const int ntiles = qs < p.Nq ? (p.Nq - qs + TQ - 1) / TQ : 0;
   // queries >= this index see every key of this wave's 32 keys
   const int full_vis_q = q_first(p, b, min(k0 + wave * 32 + 31, p.Nk - 1));
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
             const int r = 4 * g + j;
             float pv = __builtin_amdgcn_exp2f(sc[u][r] * c - l4[j]);
             const int q = qb + 32 * u + acc_row(r, lh);
-            if (!(k_ok && (prefix ? q >= my_qf : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos)))) pv = 0.0f;
+            if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))))) pv = 0.0f;
             sc[u][r] = pv;
             dp[u][r] = pv * (dp[u][r] - d4[j]);
           }
@@ -834,7 +836,7 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
                "%s: head_dim %lld unsupported (8/16/32/64, 128 for bf16)", name, (long long)D);
   FK_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B < 65536 && H < 65536 && Nq < (1LL << 30) && Nk < (1LL << 30) && B * H * ((Nq + 127) / 128) < (1LL << 31) && B * H * ((Nk + 127) / 128) < (1LL << 31),
                "%s: bad shape B=%lld H=%lld Nq=%lld Nk=%lld", name, (long long)B, (long long)H, (long long)Nq, (long long)Nk);
-  FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL || mask_kind == FK_MASK_PREFIX,
+  FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL || mask_kind == FK_MASK_PREFIX || mask_kind == FK_MASK_KEYPAD,
                "%s: mask kind %d not supported", name, mask_kind);
   FK_CHECK_ARG(mask_kind != FK_MASK_BLOCK_CAUSAL || mask_c > 0, "%s: block-causal mask needs block size > 0", name);
   const int vec = dtype == FK_BF16 ? 8 : 4;
@@ -881,7 +883,7 @@ int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
   a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_rs = o_rs;
   a.B = (int)B; a.H = (int)H; a.Nq = (int)Nq; a.Nk = (int)Nk;
   a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
-  FK_CHECK_ARG(mask_kind != FK_MASK_PREFIX || (limits && qfirst), "fk_attn_fwd: prefix mask needs limits and qfirst");
+  FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_fwd: prefix / key-padding masks need both tables");
   a.limits = limits; a.qfirst = qfirst;
   FK_ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_fwd");
@@ -908,7 +910,7 @@ int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
   a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
   FK_CHECK_ARG(!rope_table || (Nq == Nk && D % 4 == 0 && ((uintptr_t)rope_table & 15) == 0), "fk_attn_bwd: fused inverse RoPE needs self-attention (Nq == Nk)");
   a.rope_table = rope_table; a.rope_bs = rope_bs; a.rope_off = (int)rope_off;
-  FK_CHECK_ARG(mask_kind != FK_MASK_PREFIX || (limits && qfirst), "fk_attn_bwd: prefix mask needs limits and qfirst");
+  FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_bwd: prefix / key-padding masks need both tables");
   a.limits = limits; a.qfirst = qfirst;
   FK_ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_bwd");

@@ -42,31 +42,38 @@ FK_DEV float block_max(float v, float* sh) {
 }
 
 // ---- L1 / MSE ---------------------------------------------------------------------------------
+// part[blk] = sum w * f(d), part[nblk + blk] = sum w  (w = row_w[i / row_len] or 1)
 template <typename T>
-__global__ void l1_partial_kernel(const T* pred, const T* tgt, float* part, int64_t n, int squared) {
+__global__ void l1_partial_kernel(const T* pred, const T* tgt, float* part, int64_t n, int squared, const float* row_w, int64_t row_len) {
   __shared__ float sh[4];
-  float s = 0.0f;
+  float s = 0.0f, c = 0.0f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float d = to_f32<T>(pred[i]) - to_f32<T>(tgt[i]);
-    s += squared ? d * d : fabsf(d);
+    const float w = row_w ? row_w[i / row_len] : 1.0f;
+    s += w * (squared ? d * d : fabsf(d));
+    c += w;
   }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) { part[blockIdx.x] = s; part[gridDim.x + blockIdx.x] = c; }
 }
-__global__ void scalar_final_kernel(const float* part, int nparts, float* out, float scale) {
+// out[0] = sum / count, out[1] = count
+__global__ void l1_final_kernel(const float* part, int nparts, float* out) {
   __shared__ float sh[4];
-  float s = 0.0f;
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+  float s = 0.0f, c = 0.0f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) { s += part[i]; c += part[nparts + i]; }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) out[0] = s * scale;
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) { out[0] = s / c; out[1] = c; }
 }
 template <typename T>
-__global__ void l1_bwd_kernel(const T* pred, const T* tgt, const float* gout, T* dpred, int64_t n, int squared) {
-  const float g = gout[0] / (float)n;
+__global__ void l1_bwd_kernel(const T* pred, const T* tgt, const float* gout, T* dpred, int64_t n, int squared,
+                              const float* row_w, int64_t row_len, const float* loss2) {
+  const float g = gout[0] / (row_w ? loss2[1] : (float)n);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float d = to_f32<T>(pred[i]) - to_f32<T>(tgt[i]);
     const float v = squared ? 2.0f * d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
-    dpred[i] = from_f32<T>(v * g);
+    dpred[i] = from_f32<T>(v * g * (row_w ? row_w[i / row_len] : 1.0f));
   }
 }
 
@@ -167,29 +174,29 @@ extern "C" {
 int fk_version(void) { return FK_VERSION; }
 const char* fk_last_error(void) { return g_err; }
 
-size_t fk_loss_workspace_bytes(int64_t n) { return (size_t)grid_for(n, 1024) * sizeof(float); }
+size_t fk_loss_workspace_bytes(int64_t n) { return (size_t)grid_for(n, 1024) * 2 * sizeof(float); }
 
-int fk_l1_loss_fwd(const void* pred, const void* target, float* loss, int64_t n, int squared, int dtype,
-                   void* workspace, size_t workspace_bytes, void* stream) {
+int fk_l1_loss_fwd(const void* pred, const void* target, float* loss2, int64_t n, int squared, const float* row_weight,
+                   int64_t row_len, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_l1_loss_fwd: bad dtype %d", dtype);
-  FK_CHECK_ARG(pred && target && loss && n > 0, "fk_l1_loss_fwd: bad arguments");
+  FK_CHECK_ARG(pred && target && loss2 && n > 0 && (!row_weight || (row_len > 0 && n % row_len == 0)), "fk_l1_loss_fwd: bad arguments");
   const unsigned nb = grid_for(n, 1024);
-  FK_CHECK_ARG(workspace && workspace_bytes >= nb * sizeof(float), "fk_l1_loss_fwd: workspace too small");
+  FK_CHECK_ARG(workspace && workspace_bytes >= (size_t)nb * 2 * sizeof(float), "fk_l1_loss_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == FK_BF16) hipLaunchKernelGGL(l1_partial_kernel<bf16_t>, dim3(nb), dim3(TPB), 0, s, (const bf16_t*)pred, (const bf16_t*)target, (float*)workspace, n, squared);
-  else hipLaunchKernelGGL(l1_partial_kernel<float>, dim3(nb), dim3(TPB), 0, s, (const float*)pred, (const float*)target, (float*)workspace, n, squared);
+  if (dtype == FK_BF16) hipLaunchKernelGGL(l1_partial_kernel<bf16_t>, dim3(nb), dim3(TPB), 0, s, (const bf16_t*)pred, (const bf16_t*)target, (float*)workspace, n, squared, row_weight, row_len);
+  else hipLaunchKernelGGL(l1_partial_kernel<float>, dim3(nb), dim3(TPB), 0, s, (const float*)pred, (const float*)target, (float*)workspace, n, squared, row_weight, row_len);
   FK_CHECK_LAUNCH("fk_l1_loss_fwd");
-  hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(TPB), 0, s, (const float*)workspace, (int)nb, loss, 1.0f / (float)n);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(TPB), 0, s, (const float*)workspace, (int)nb, loss2);
   FK_CHECK_LAUNCH("fk_l1_loss_fwd(final)");
   return FK_OK;
 }
 int fk_l1_loss_bwd(const void* pred, const void* target, const float* grad_out, void* dpred, int64_t n, int squared,
-                   int dtype, void* stream) {
+                   const float* row_weight, int64_t row_len, const float* loss2, int dtype, void* stream) {
   FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_l1_loss_bwd: bad dtype %d", dtype);
-  FK_CHECK_ARG(pred && target && grad_out && dpred && n > 0, "fk_l1_loss_bwd: bad arguments");
+  FK_CHECK_ARG(pred && target && grad_out && dpred && n > 0 && (!row_weight || (row_len > 0 && loss2)), "fk_l1_loss_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == FK_BF16) hipLaunchKernelGGL(l1_bwd_kernel<bf16_t>, dim3(grid_for(n, 4096)), dim3(TPB), 0, s, (const bf16_t*)pred, (const bf16_t*)target, grad_out, (bf16_t*)dpred, n, squared);
-  else hipLaunchKernelGGL(l1_bwd_kernel<float>, dim3(grid_for(n, 4096)), dim3(TPB), 0, s, (const float*)pred, (const float*)target, grad_out, (float*)dpred, n, squared);
+  if (dtype == FK_BF16) hipLaunchKernelGGL(l1_bwd_kernel<bf16_t>, dim3(grid_for(n, 4096)), dim3(TPB), 0, s, (const bf16_t*)pred, (const bf16_t*)target, grad_out, (bf16_t*)dpred, n, squared, row_weight, row_len, loss2);
+  else hipLaunchKernelGGL(l1_bwd_kernel<float>, dim3(grid_for(n, 4096)), dim3(TPB), 0, s, (const float*)pred, (const float*)target, grad_out, (float*)dpred, n, squared, row_weight, row_len, loss2);
   FK_CHECK_LAUNCH("fk_l1_loss_bwd");
   return FK_OK;
 }

@@ -171,13 +171,13 @@ class AttnBranch(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, pw, pb, qkv_b, spec, *qkv_w):
-        H, D, mask, rope, residual, eps = spec
+        H, D, mask, rope, residual, eps, nkind = spec
         B, N, d = x.shape
         M = B * N
         x2 = x.view(M, d)
         has_ln = ln_w is not None
         if has_ln:
-            h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps)
+            h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps, nkind)
         else:
             h, mean, rstd = x2, None, None
         HD = H * D
@@ -201,7 +201,7 @@ class AttnBranch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        H, D, mask, rope, residual, eps = ctx.spec
+        H, D, mask, rope, residual, eps, nkind = ctx.spec
         sv = ctx.saved_tensors
         x, ln_w, pw = sv[0], sv[1], sv[2]
         qkv_w = sv[3:3 + ctx.nw]
@@ -230,7 +230,7 @@ class AttnBranch(torch.autograd.Function):
         dw = K.gemm_tn(dqkv, h)
         dqb = K.colsum(dqkv) if has_qb else None
         if ctx.has_ln:
-            dx, dg, db = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, want_beta=has_lnb)
+            dx, dg, db = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, kind=nkind, want_beta=has_lnb)
         else:
             dx, dg, db = (K.add(dh, dy2) if residual else dh), None, None
         return (dx.view(B, N, d), dg, db, dpw, dpb, dqb, None, *_split_rows(dw, qkv_w))
@@ -287,13 +287,13 @@ class MlpBranch(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, up_w, up_b, gate_w, down_w, down_b, spec):
-        residual, eps = spec
+        residual, eps, nkind = spec
         shp = x.shape
         d = shp[-1]
         x2 = x.reshape(-1, d)
         has_ln = ln_w is not None
         if has_ln:
-            h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps)
+            h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps, nkind)
         else:
             h, mean, rstd = x2, None, None
         fused = gate_w is not None and up_b is None and up_w.shape[0] % 8 == 0
@@ -312,7 +312,7 @@ class MlpBranch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        residual, eps = ctx.spec
+        residual, eps, nkind = ctx.spec
         x, ln_w, up_w, gate_w, down_w, h, mean, rstd, a, g = ctx.saved_tensors
         has_lnb, has_ub, gated, has_db = ctx.flags
         shp = x.shape
@@ -335,7 +335,7 @@ class MlpBranch(torch.autograd.Function):
             dups = _split_rows(K.gemm_tn(da, h), ups)
         dub = K.colsum(da) if has_ub else None
         if ctx.has_ln:
-            dx, dgam, dbet = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, want_beta=has_lnb)
+            dx, dgam, dbet = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, kind=nkind, want_beta=has_lnb)
         else:
             dx, dgam, dbet = (K.add(dh, dy2) if residual else dh), None, None
         return (dx.view(shp), dgam, dbet, dups[0], dub, dups[1] if gated else None, ddown, ddb, None)
@@ -451,19 +451,22 @@ class ExpandQueries(torch.autograd.Function):
 
 
 class L1Loss(torch.autograd.Function):
+    """mean |d| (L1) or d^2 (MSE); optional per-row weights give the masked mean of SimpleMAE (models/simple_mae:393-395)."""
+
     @staticmethod
-    def forward(ctx, pred, target, squared):
+    def forward(ctx, pred, target, squared, row_weight=None):
         tgt = target if target.dtype == pred.dtype else K.cast(target.contiguous(), pred.dtype)
         p = pred.contiguous()
+        loss2 = K.l1_loss_fwd(p, tgt.contiguous(), squared, row_weight)
         ctx.squared = squared
-        ctx.save_for_backward(p, tgt.contiguous())
-        return K.l1_loss_fwd(p, tgt.contiguous(), squared)[0]
+        ctx.save_for_backward(p, tgt.contiguous(), row_weight, loss2)
+        return loss2[0]
 
     @staticmethod
     def backward(ctx, gout):
-        p, tgt = ctx.saved_tensors
+        p, tgt, row_weight, loss2 = ctx.saved_tensors
         g = gout.reshape(1).float().contiguous()
-        return K.l1_loss_bwd(p, tgt, g, ctx.squared), None, None
+        return K.l1_loss_bwd(p, tgt, g, ctx.squared, row_weight, loss2), None, None, None
 
 
 class CrossEntropy(torch.autograd.Function):
@@ -496,8 +499,8 @@ def l1_loss(pred: Tensor, target: Tensor) -> Tensor:
     return L1Loss.apply(pred, target, False)
 
 
-def mse_loss(pred: Tensor, target: Tensor) -> Tensor:
-    return L1Loss.apply(pred, target, True)
+def mse_loss(pred: Tensor, target: Tensor, row_weight: Optional[Tensor] = None) -> Tensor:
+    return L1Loss.apply(pred, target, True, row_weight)
 
 
 # --------------------------------------------------------------------------------------------- MAE pieces

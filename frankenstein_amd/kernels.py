@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_NONE, MASK_PREFIX, NORM_LAYER, NORM_RMS, call, lib
+from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_KEYPAD, MASK_NONE, MASK_PREFIX, NORM_LAYER, NORM_RMS, call, lib
 
 Tensor = torch.Tensor
 
@@ -175,8 +175,13 @@ class Mask:
         self.kind, self.c, self.q_off, self.k_off, self.limits, self.qfirst = kind, c, q_off, k_off, limits, qfirst
 
     def sliced(self, n_full_q: int, n_full_k: int, t_q: int, t_k: int) -> "Mask":
-        assert self.kind != MASK_PREFIX or (n_full_q == t_q and n_full_k == t_k), "prefix masks cannot be sliced"
+        assert self.kind not in (MASK_PREFIX, MASK_KEYPAD) or (n_full_q == t_q and n_full_k == t_k), "table masks cannot be sliced"
         return Mask(self.kind, self.c, self.q_off + n_full_q - t_q, self.k_off + n_full_k - t_k, self.limits, self.qfirst)
+
+    @staticmethod
+    def from_padding(q_valid: Tensor, k_valid: Tensor) -> "Mask":
+        """visible(i, j) = q_valid[b, i] & k_valid[b, j]  (create_attention_mask_from_padding, models/simple_mae:228-236)."""
+        return Mask(MASK_KEYPAD, 0, 0, 0, q_valid.to(torch.int32).contiguous(), k_valid.to(torch.int32).contiguous())
 
     @staticmethod
     def from_token_ids(q_ids: Tensor, k_ids: Tensor, block: int) -> "Mask":
@@ -396,20 +401,25 @@ def copy2d(src: Tensor, dst: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------- losses
-def l1_loss_fwd(pred: Tensor, target: Tensor, squared: bool = False) -> Tensor:
+def l1_loss_fwd(pred: Tensor, target: Tensor, squared: bool = False, row_weight: Optional[Tensor] = None) -> Tensor:
+    """-> loss2 fp32[2] = {mean (weighted) |d| or d^2, weight sum}; row_weight: fp32 [rows] with rows = numel / last dim."""
     assert pred.is_contiguous() and target.is_contiguous() and pred.shape == target.shape and pred.dtype == target.dtype
-    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    loss2 = torch.empty(2, dtype=torch.float32, device=pred.device)
+    row_len = pred.shape[-1]
+    if row_weight is not None:
+        assert row_weight.dtype == torch.float32 and row_weight.is_contiguous() and row_weight.numel() * row_len == pred.numel()
     ws, nb = _ws(lib().fk_loss_workspace_bytes(pred.numel()), pred.device)
-    call("fk_l1_loss_fwd", pred.data_ptr(), target.data_ptr(), loss.data_ptr(), pred.numel(), int(squared),
-         fk_dtype(pred), _ptr(ws), nb, _stream())
-    return loss
+    call("fk_l1_loss_fwd", pred.data_ptr(), target.data_ptr(), loss2.data_ptr(), pred.numel(), int(squared), _ptr(row_weight),
+         row_len, fk_dtype(pred), _ptr(ws), nb, _stream())
+    return loss2
 
 
-def l1_loss_bwd(pred: Tensor, target: Tensor, gout: Tensor, squared: bool = False) -> Tensor:
+def l1_loss_bwd(pred: Tensor, target: Tensor, gout: Tensor, squared: bool = False, row_weight: Optional[Tensor] = None,
+                loss2: Optional[Tensor] = None) -> Tensor:
     assert gout.dtype == torch.float32 and gout.numel() == 1
     d = torch.empty_like(pred)
     call("fk_l1_loss_bwd", pred.data_ptr(), target.data_ptr(), gout.data_ptr(), d.data_ptr(), pred.numel(), int(squared),
-         fk_dtype(pred), _stream())
+         _ptr(row_weight), pred.shape[-1], _ptr(loss2), fk_dtype(pred), _stream())
     return d
 
 

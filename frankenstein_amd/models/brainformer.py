@@ -179,6 +179,10 @@ class RMSNorm(nn.Module):
         return E.LayerNormFn.apply(_prep(x), self.weight, None, self.eps, K.NORM_RMS)
 
 
+def _norm_kind(ln) -> int:
+    return K.NORM_RMS if isinstance(ln, RMSNorm) else K.NORM_LAYER
+
+
 class MLP(nn.Module):
     """SwiGLU: w2(silu(w1 x) * w3 x), no biases."""
 
@@ -189,9 +193,9 @@ class MLP(nn.Module):
         self.w3 = Linear(config.dim, config.hidden_dim, bias=False)
 
     def branch(self, x, ln: Optional[nn.LayerNorm], residual: bool):
-        return E.MlpBranch.apply(x, None if ln is None else ln.weight, None if ln is None else ln.bias,
+        return E.MlpBranch.apply(x, None if ln is None else ln.weight, None if ln is None else getattr(ln, 'bias', None),
                                  self.w1.weight, None, self.w3.weight, self.w2.weight, None,
-                                 (residual, 0.0 if ln is None else ln.eps))
+                                 (residual, 0.0 if ln is None else ln.eps, _norm_kind(ln)))
 
     def forward(self, x) -> torch.Tensor:
         return self.branch(_prep(x), None, False)
@@ -213,8 +217,8 @@ class CausalSelfAttention(nn.Module):
     def branch(self, x, attn_mask, rope, ln: Optional[nn.LayerNorm], residual: bool):
         T = x.shape[1]
         spec = (self.n_heads, self.head_dim, resolve_mask(attn_mask, T, T),
-                None if rope is None else E.Rope(rope), residual, 0.0 if ln is None else ln.eps)
-        return E.AttnBranch.apply(x, None if ln is None else ln.weight, None if ln is None else ln.bias,
+                None if rope is None else E.Rope(rope), residual, 0.0 if ln is None else ln.eps, _norm_kind(ln))
+        return E.AttnBranch.apply(x, None if ln is None else ln.weight, None if ln is None else getattr(ln, 'bias', None),
                                   self.project.weight, None, None, spec, self.qw.weight, self.kw.weight, self.vw.weight)
 
     def forward(self, x, attn_mask, rope, kv_cache=None):

@@ -49,7 +49,7 @@ class CausalSelfAttention(nn.Module):
     def branch(self, x, ln, residual: bool):
         if self.dropout and self.training:
             raise NotImplementedError("attention/residual dropout > 0 is not implemented in the fused kernels")
-        spec = (self.n_head, self.n_embd // self.n_head, CAUSAL, None, residual, 0.0 if ln is None else ln.eps)
+        spec = (self.n_head, self.n_embd // self.n_head, CAUSAL, None, residual, 0.0 if ln is None else ln.eps, K.NORM_LAYER)
         return E.AttnBranch.apply(x, None if ln is None else ln.weight, None if ln is None else ln.bias,
                                   self.c_proj.weight, self.c_proj.bias, self.c_attn.bias, spec, self.c_attn.weight)
 
@@ -70,7 +70,7 @@ class MLP(nn.Module):
             raise NotImplementedError("MLP dropout > 0 is not implemented in the fused kernels")
         return E.MlpBranch.apply(x, None if ln is None else ln.weight, None if ln is None else ln.bias,
                                  self.c_fc.weight, self.c_fc.bias, None, self.c_proj.weight, self.c_proj.bias,
-                                 (residual, 0.0 if ln is None else ln.eps))
+                                 (residual, 0.0 if ln is None else ln.eps, K.NORM_LAYER))
 
     def forward(self, x):
         return self.branch(_prep(x), None, False)

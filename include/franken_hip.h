@@ -31,7 +31,7 @@ extern "C" {
 #define FK_EUNSUPPORTED (-3)
 
 enum { FK_F32 = 0, FK_BF16 = 1 };
-enum { FK_MASK_NONE = 0, FK_MASK_CAUSAL = 1, FK_MASK_BLOCK_CAUSAL = 2, FK_MASK_PREFIX = 3 };
+enum { FK_MASK_NONE = 0, FK_MASK_CAUSAL = 1, FK_MASK_BLOCK_CAUSAL = 2, FK_MASK_PREFIX = 3, FK_MASK_KEYPAD = 4 };
 enum { FK_NORM_LAYER = 0, FK_NORM_RMS = 1 };
 enum { FK_ACT_SWIGLU = 0, FK_ACT_GELU = 1 };
 
@@ -76,7 +76,9 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
  * mask: NONE | CAUSAL (k + k_off <= q + q_off) | BLOCK_CAUSAL ((k + k_off)/mask_c <= (q + q_off)/mask_c), the
  * analytic form of build_advanced_causal_mask (models/brainformer.py:93-111) incl. the [-t_q:, -t_k:] slice (:160-162).
  * PREFIX (per-sample masks of sorted token subsets, MAE's get_sub_att_matrix models/brainformer.py:392-413):
- * visible(q,k) = k < limits[b,q] <=> q >= qfirst[b,k], int32 tables from fk_prefix_mask.  Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
+ * visible(q,k) = k < limits[b,q] <=> q >= qfirst[b,k], int32 tables from fk_prefix_mask.
+ * KEYPAD (padding mask of models/simple_mae:228-236,349-352): visible(q,k) = limits[b,q] != 0 && qfirst[b,k] != 0, i.e. the two
+ * int32 tables are the query / key validity flags.  Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
  * Q/K/V's strides; delta_ws is [B,H,Nq] fp32 scratch.  rope_table != NULL (self-attention only) additionally applies the
  * inverse RoPE (rotation by -angle at position rope_off + index) to dQ and dK as they are stored = apply_rope's backward.                                                        */
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
@@ -154,15 +156,16 @@ int fk_gpt_embed_fwd(const int64_t* idx, const void* prefix, const float* wte, c
 int fk_gpt_embed_bwd_wte(const int64_t* idx, const void* dout, float* dwte, int64_t B, int64_t t_ctx, int64_t t_words,
                          int64_t dim, int64_t vocab, int dtype, void* stream);
 
-/* ---- losses.  L1 (F.l1_loss, models/brainformer.py:557) / MSE (F.mse_loss, :473), mean reduction: loss fp32[1];
+/* ---- losses.  L1 (F.l1_loss, models/brainformer.py:557) / MSE (F.mse_loss, :473), mean reduction: loss2 fp32[2] = {loss, weight sum};
+ *      row_weight (nullable, one weight per row of row_len elements) gives the masked mean of models/simple_mae:393-395;
  *      bwd: dpred = grad_out[0] * d(loss)/d(pred) with grad_out a DEVICE scalar (no host sync).
  *      CE (F.cross_entropy ignore_index mean, models/gpt2_model.py:210; train_brainformer.ipynb cell 3):
  *      logits [rows, V] (ld), targets int64 [rows]; loss2 = {mean nll over valid rows, #valid}; row_lse [rows].  */
 size_t fk_loss_workspace_bytes(int64_t n);
-int fk_l1_loss_fwd(const void* pred, const void* target, float* loss, int64_t n, int squared, int dtype,
-                   void* workspace, size_t workspace_bytes, void* stream);
+int fk_l1_loss_fwd(const void* pred, const void* target, float* loss2, int64_t n, int squared, const float* row_weight,
+                   int64_t row_len, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 int fk_l1_loss_bwd(const void* pred, const void* target, const float* grad_out, void* dpred, int64_t n, int squared,
-                   int dtype, void* stream);
+                   const float* row_weight, int64_t row_len, const float* loss2, int dtype, void* stream);
 size_t fk_ce_workspace_bytes(int64_t rows);
 int fk_ce_loss_fwd(const void* logits, int64_t ld, const int64_t* targets, float* loss2, float* row_lse, int64_t rows,
                    int64_t V, int64_t ignore_index, int dtype, void* workspace, size_t workspace_bytes, void* stream);

@@ -376,3 +376,87 @@ def mae_forward(sd, x: Tensor, cfg, masked: Tensor, unmasked: Tensor, p: str = "
     pred = linear(dec[br, masked], sd[p + "to_signals.weight"], sd[p + "to_signals.bias"])
     loss = ((pred - tok[br, masked]) ** 2).mean()
     return loss, pred
+
+
+# --------------------------------------------------------------------------- SimpleMAE (BASELINE.json configs[4])
+def simple_encoder_config(**kw) -> SimpleNamespace:
+    """notebooks/simple_mae.ipynb cell 1 (SimpleEncoderConfig)."""
+    d = dict(block_size=768, patch_size=128, n_layers=6, dim=256, hidden_dim=1024, head_dim=32, n_heads=4, n_kv_heads=4,
+             rope_theta=10000)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def simple_mae_config(**kw) -> SimpleNamespace:
+    """notebooks/simple_mae.ipynb cell 1 (SimpleMAEConfig)."""
+    d = dict(n_layers=2, dim=256, hidden_dim=1024, head_dim=32, n_heads=8, n_kv_heads=8, rope_theta=10000)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def rms_block_shapes(q: str, cfg) -> Dict[str, tuple]:
+    d, hd, H = cfg.dim, cfg.head_dim * cfg.n_heads, cfg.hidden_dim
+    return {q + "ln_1.weight": (d,), q + "ln_2.weight": (d,), q + "attn.qw.weight": (hd, d), q + "attn.kw.weight": (hd, d),
+            q + "attn.vw.weight": (hd, d), q + "attn.project.weight": (d, hd), q + "mlp.w1.weight": (H, d),
+            q + "mlp.w2.weight": (d, H), q + "mlp.w3.weight": (H, d)}
+
+
+def simple_mae_shapes(ecfg, mcfg) -> Dict[str, tuple]:
+    s = {"encoder.transformer.emb.weight": (ecfg.dim, ecfg.patch_size), "encoder.transformer.emb.bias": (ecfg.dim,),
+         "encoder.transformer.ln_f.weight": (ecfg.dim,), "encoder.transformer.ln_f.bias": (ecfg.dim,),
+         "decoder.emb.weight": (mcfg.dim, ecfg.dim), "decoder.emb.bias": (mcfg.dim,), "mask_token": (mcfg.dim,),
+         "decoder_pos_emb.weight": (ecfg.block_size, mcfg.dim), "to_signals.weight": (ecfg.patch_size, mcfg.dim),
+         "to_signals.bias": (ecfg.patch_size,)}
+    for i in range(ecfg.n_layers):
+        s.update(rms_block_shapes(f"encoder.transformer.h.{i}.", ecfg))
+    for i in range(mcfg.n_layers):
+        s.update(rms_block_shapes(f"decoder.h.{i}.", mcfg))
+    return s
+
+
+def rms_block(sd, p: str, x: Tensor, cfg, mask, ang) -> Tensor:
+    """models/simple_mae:194-205 (RMSNorm eps 1e-6, no bias)."""
+    h = rms_norm(x, sd[p + "ln_1.weight"])
+    x = x + self_attention(sd, p + "attn.", h, cfg.n_heads, cfg.head_dim, mask, ang)
+    h = rms_norm(x, sd[p + "ln_2.weight"])
+    return x + swiglu_mlp(sd, p + "mlp.", h)
+
+
+def sdpa_zero_fully_masked(q, k, v, mask):
+    """torch >= 2.1 CPU SDPA gives 0 (not NaN) for query rows whose keys are all masked (padding rows)."""
+    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
+    s = s.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.nan_to_num(p, nan=0.0) @ v
+
+
+def simple_mae_forward(sd, x: Tensor, ecfg, mcfg, masked: Tensor, unmasked: Tensor):
+    """models/simple_mae:338-407 with the random index sets given.  Returns (loss, predictions at the masked frames)."""
+    B, T, _ = x.shape
+    br = torch.arange(B)[:, None]
+    valid = ~(x == 0).all(dim=2)
+    m_all = (valid[:, None, :] & valid[:, :, None])[:, None]
+    vu = valid[br, unmasked]
+    m_u = (vu[:, None, :] & vu[:, :, None])[:, None]
+    ang = rope_angles(ecfg.head_dim, ecfg.block_size, ecfg.rope_theta).expand(B, -1, -1)[br, unmasked]
+    global sdpa
+    keep = sdpa
+    sdpa = sdpa_zero_fully_masked
+    try:
+        h = linear(x[br, unmasked], sd["encoder.transformer.emb.weight"], sd["encoder.transformer.emb.bias"])
+        for i in range(ecfg.n_layers):
+            h = rms_block(sd, f"encoder.transformer.h.{i}.", h, ecfg, m_u, ang)
+        h = layer_norm(h, sd["encoder.transformer.ln_f.weight"], sd["encoder.transformer.ln_f.bias"])
+        h = linear(h, sd["decoder.emb.weight"], sd["decoder.emb.bias"])
+        dec = torch.zeros(B, T, mcfg.dim).index_put((br, unmasked), h)
+        dec = dec.index_put((br, masked), sd["mask_token"].expand(B, masked.shape[1], -1))
+        dec = dec + sd["decoder_pos_emb.weight"][torch.cat([unmasked, masked], 1)]
+        for i in range(mcfg.n_layers):
+            dec = rms_block(sd, f"decoder.h.{i}.", dec, mcfg, m_all, None)
+    finally:
+        sdpa = keep
+    pred_all = linear(dec, sd["to_signals.weight"], sd["to_signals.bias"])
+    pred, real = pred_all[br, masked], x[br, masked]
+    w = valid[br, masked]
+    loss = (((pred - real) ** 2) * w[..., None]).sum() / (w.sum() * x.shape[2])
+    return loss, pred

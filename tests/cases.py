@@ -95,3 +95,9 @@ def unpatch(tok, C, P):
     """'b (t c) p -> b (t p) c' (models/brainformer.py:372)"""
     B, N, _ = tok.shape
     return tok.view(B, N // C, C, P).permute(0, 1, 3, 2).reshape(B, (N // C) * P, C)
+
+
+def simple_mae_small():
+    ecfg = R.simple_encoder_config(block_size=40, patch_size=24, n_layers=2, dim=64, hidden_dim=128, head_dim=16, n_heads=4, n_kv_heads=4)
+    mcfg = R.simple_mae_config(n_layers=2, dim=48, hidden_dim=96, head_dim=8, n_heads=4, n_kv_heads=4)
+    return ecfg, mcfg

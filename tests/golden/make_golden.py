@@ -273,6 +273,32 @@ def main():
          recon=recon.detach().numpy(), binary_mask=bmask.detach().numpy(),
          **{"grad/" + k: v.numpy() for k, v in grads_of(mae).items()})
 
+    # ---- simple_mae_small: models/simple_mae (no .py suffix) + the notebook-only config dataclasses; two samples carry a
+    #      zero-padded tail (utils/data_utils.py:243-267 pads with 0) so the padding mask / masked loss are exercised
+    import contextlib
+    import dataclasses
+    import io
+    sm = importlib.machinery.SourceFileLoader("ref_simple_mae", str(REF / "models" / "simple_mae")).load_module()
+    ns3 = dict(dataclass=dataclasses.dataclass, Serializable=object)
+    exec("".join(json.load(open(REF / "notebooks" / "simple_mae.ipynb"))["cells"][1]["source"]), ns3)
+    ecfg = ns3["SimpleEncoderConfig"](block_size=40, patch_size=24, n_layers=2, dim=64, hidden_dim=128, head_dim=16,
+                                      n_heads=4, n_kv_heads=4)
+    mcfg = ns3["SimpleMAEConfig"](n_layers=2, dim=48, hidden_dim=96, head_dim=8, n_heads=4, n_kv_heads=4)
+    m = sm.SimpleMAE(ecfg, mcfg).float()
+    load_synth(m, skip=())
+    x = torch.from_numpy(synth.make_inputs(3, 40, 24))
+    x[1, 33:] = 0.0
+    x[2, 38:] = 0.0
+    torch.manual_seed(321)
+    masked, unmasked = m.get_masking_indices(0.75, x)
+    torch.manual_seed(321)
+    with contextlib.redirect_stdout(io.StringIO()):      # the reference prints debug shapes in forward
+        loss, recon, bmask = m(x, masking_ratio=0.75, return_preds=True)
+    loss.backward()
+    save("simple_mae_small", loss=np.array(float(loss.detach())), masked=masked.numpy(), unmasked=unmasked.numpy(), x=x.numpy(),
+         recon=recon.detach().numpy(), binary_mask=bmask.detach().numpy(),
+         **{"grad/" + k: v.numpy() for k, v in grads_of(m).items()})
+
 
 if __name__ == "__main__":
     main()

@@ -296,3 +296,25 @@ def test_mae_small_fp32(golden):
     assert none is None and torch.isfinite(l2)
     ma, un = m.get_masking_indices(0.75, torch.zeros(3, 128, 4, device="cuda"))
     assert ma.shape == (3, 96) and un.shape == (3, 32) and bool((ma[:, 1:] > ma[:, :-1]).all())
+
+
+def test_simple_mae_small_fp32(golden):
+    """BASELINE.json configs[4]: SimpleMAE (models/simple_mae) incl. zero-padded frames, vs the reference golden."""
+    from frankenstein_amd.models import simple_mae as sm
+    z = golden("simple_mae_small")
+    ecfg = sm.SimpleEncoderConfig(block_size=40, patch_size=24, n_layers=2, dim=64, hidden_dim=128, head_dim=16, n_heads=4, n_kv_heads=4)
+    mcfg = sm.SimpleMAEConfig(n_layers=2, dim=48, hidden_dim=96, head_dim=8, n_heads=4, n_kv_heads=4)
+    m = sm.SimpleMAE(ecfg, mcfg)
+    oe, om = C.simple_mae_small()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dict(R.simple_mae_shapes(oe, om))
+    m = load_synth(m, skip=())
+    x = torch.from_numpy(z["x"]).cuda()
+    idx = (torch.from_numpy(z["masked"]).cuda(), torch.from_numpy(z["unmasked"]).cuda())
+    loss, recon, bmask = m(x, masking_ratio=0.75, return_preds=True, indices=idx)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    np.testing.assert_allclose(recon.cpu().numpy(), z["recon"], atol=1e-4)
+    np.testing.assert_array_equal(bmask.cpu().numpy(), z["binary_mask"])
+    loss.backward()
+    check_full_grads(m, z)
+    l2, _ = m(x)                                    # random index sets drawn on the device
+    assert torch.isfinite(l2)

@@ -165,3 +165,19 @@ def test_mae_small(golden):
     bm = torch.zeros_like(tok).index_put((br, masked), torch.ones(3, masked.shape[1], 4))
     np.testing.assert_array_equal(C.unpatch(bm, 16, 4).numpy(), z["binary_mask"])
     check_grads(grads(loss, sd), z)
+
+
+def test_simple_mae_small(golden):
+    """BASELINE.json configs[4] (models/simple_mae): padding-aware masks, RMSNorm blocks, masked + non-padded MSE."""
+    z = golden("simple_mae_small")
+    ecfg, mcfg = C.simple_mae_small()
+    sd = leafify(C.state(R.simple_mae_shapes(ecfg, mcfg)))
+    x = torch.from_numpy(z["x"])
+    assert bool((x[1, 33:] == 0).all()) and bool((x[2, 38:] == 0).all())
+    masked, unmasked = torch.from_numpy(z["masked"]), torch.from_numpy(z["unmasked"])
+    loss, pred = R.simple_mae_forward(sd, x, ecfg, mcfg, masked, unmasked)
+    assert abs(float(loss) - float(z["loss"])) < 2e-6
+    br = torch.arange(3)[:, None]
+    rec = torch.zeros_like(x).index_put((br, masked), pred.detach()).index_put((br, unmasked), x[br, unmasked])
+    np.testing.assert_allclose(rec.numpy(), z["recon"], atol=2e-5)
+    check_grads(grads(loss, sd), z)
