@@ -192,6 +192,12 @@ __global__ void copy2d_kernel(const T* src, int64_t lds, T* dst, int64_t ldd, in
     dst[(i / cols) * ldd + (i % cols)] = src[(i / cols) * lds + (i % cols)];
 }
 
+__global__ void add2d_kernel(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols) {
+  const int64_t total = rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    dst[(i / cols) * ldd + (i % cols)] += src[(i / cols) * lds + (i % cols)];
+}
+
 // ---------------------------------------------------------------------------------------------- embeddings
 // out[r, :] = (src_sel ? prefix row : table[idx]) + pos[t]   for the GPT prefix-concat embedding
 template <typename T>
@@ -404,6 +410,13 @@ int fk_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows
   if (dtype == FK_BF16) hipLaunchKernelGGL(copy2d_kernel<bf16_t>, dim3(grid_for(rows * cols, 16384)), dim3(TPB), 0, s, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, rows, cols);
   else hipLaunchKernelGGL(copy2d_kernel<float>, dim3(grid_for(rows * cols, 16384)), dim3(TPB), 0, s, (const float*)src, lds, (float*)dst, ldd, rows, cols);
   FK_CHECK_LAUNCH("fk_copy2d");
+  return FK_OK;
+}
+
+int fk_add2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream) {
+  FK_CHECK_ARG(src && dst && rows > 0 && cols > 0, "fk_add2d: bad arguments");
+  hipLaunchKernelGGL(add2d_kernel, dim3(grid_for(rows * cols, 16384)), dim3(TPB), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, cols);
+  FK_CHECK_LAUNCH("fk_add2d");
   return FK_OK;
 }
 

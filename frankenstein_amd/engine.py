@@ -43,6 +43,65 @@ def bump_weight_epoch() -> None:
     _EPOCH += 1
 
 
+# --------------------------------------------------------------------------------------------- weight-gradient stream
+# dW = dY^T X GEMMs do not feed the rest of the backward: with a flat gradient arena (train_utils.ParamArena) they are
+# accumulated straight into the arena on a SECOND HIP stream, so they run concurrently with the dX chain / attention
+# backward of the following layers (MFMA-light, memory-light kernels fill each other's stalls).  The optimizer joins the
+# stream before the update; DP buckets are all-reduced from that stream (GradSync).  Without an arena: plain returns.
+_WGRAD_STREAM = None
+
+
+def enable_wgrad_stream(on: bool = True):
+    global _WGRAD_STREAM
+    _WGRAD_STREAM = torch.cuda.Stream() if on else None
+    return _WGRAD_STREAM
+
+
+def wgrad_stream():
+    return _WGRAD_STREAM
+
+
+def _arena_grad(p: Tensor):
+    g = p.grad
+    return g if (g is not None and getattr(p, "_fk_arena", False) and g.is_contiguous()) else None
+
+
+def wgrad(a: Tensor, b: Tensor, params: Sequence[Tensor], swiglu_interleaved: bool = False):
+    """Gradients of the row-concatenated weights `params` = a^T b ([sum N, K], fp32).  Returns a list aligned with params:
+    tensors (caller hands them to autograd) or Nones when the result was accumulated directly into the arena."""
+    side = _WGRAD_STREAM
+    grads = [_arena_grad(p) for p in params]
+    if side is None or any(g is None for g in grads):
+        dw = K.gemm_tn(a, b)
+        if swiglu_interleaved:
+            return list(_deinterleave_rows(dw, params[0].shape[0]))
+        return _split_rows(dw, params)
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    a.record_stream(side)
+    b.record_stream(side)
+    with torch.cuda.stream(side):
+        Kd = b.shape[1]
+        adjacent = all(grads[i + 1].data_ptr() == grads[i].data_ptr() + grads[i].numel() * 4 for i in range(len(grads) - 1))
+        if swiglu_interleaved:
+            dw = K.gemm_tn(a, b)                                   # [2H, K] interleaved rows
+            H = params[0].shape[0]
+            v = dw.view(H // 4, 8 * Kd)
+            K.add2d_(grads[0].view(H // 4, 4 * Kd), v[:, :4 * Kd])
+            K.add2d_(grads[1].view(H // 4, 4 * Kd), v[:, 4 * Kd:])
+        elif adjacent:
+            n = sum(p.shape[0] for p in params)
+            out = torch.as_strided(grads[0], (n, Kd), (Kd, 1))
+            K.gemm_tn(a, b, out=out, accumulate=True)
+        else:
+            dw = K.gemm_tn(a, b)
+            for g, part in zip(grads, _split_rows(dw, params)):
+                K.add2d_(g.view(part.shape), part)
+    # autograd still runs the parameters' post-accumulate-grad hooks (GradSync) after this Function returns, once per
+    # backward and after the last use of a shared weight, so bucket readiness needs no extra signalling here
+    return [None] * len(params)
+
+
 # --------------------------------------------------------------------------------------------- shadows
 class _Shadow:
     __slots__ = ("stamp", "tensor")
@@ -214,7 +273,7 @@ class AttnBranch(torch.autograd.Function):
             h = x2
         dy2 = dy.contiguous().view(M, -1)
         do = K.gemm_nt(dy2, shadow([pw], transpose=True))
-        dpw = K.gemm_tn(dy2, o.view(M, HD))
+        (dpw,) = wgrad(dy2, o.view(M, HD), [pw])
         dpb = K.colsum(dy2) if has_pb else None
         dqkv = torch.empty_like(qkv)
         qkv3, dqkv3 = qkv.view(B, N, 3 * HD), dqkv.view(B, N, 3 * HD)
@@ -227,13 +286,13 @@ class AttnBranch(torch.autograd.Function):
             if rope is not None:
                 K.rope_(dqkv3, 2 * H, D, rope.table, rope.pos_off(N), conj=True)
         dh = K.gemm_nt(dqkv, shadow(qkv_w, transpose=True))
-        dw = K.gemm_tn(dqkv, h)
+        dws = wgrad(dqkv, h, list(qkv_w))
         dqb = K.colsum(dqkv) if has_qb else None
         if ctx.has_ln:
             dx, dg, db = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, kind=nkind, want_beta=has_lnb)
         else:
             dx, dg, db = (K.add(dh, dy2) if residual else dh), None, None
-        return (dx.view(B, N, d), dg, db, dpw, dpb, dqb, None, *_split_rows(dw, qkv_w))
+        return (dx.view(B, N, d), dg, db, dpw, dpb, dqb, None, *dws)
 
 
 class CrossAttnBranch(torch.autograd.Function):
@@ -265,7 +324,7 @@ class CrossAttnBranch(torch.autograd.Function):
         x2, c2 = x.view(B * T, d), context.view(B * Nc, d)
         dy2 = dy.contiguous().view(B * T, d)
         do = K.gemm_nt(dy2, shadow([pw], transpose=True))
-        dpw = K.gemm_tn(dy2, o.view(B * T, HD))
+        (dpw,) = wgrad(dy2, o.view(B * T, HD), [pw])
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         kv3, dkv3 = kv.view(B, Nc, 2 * HD), dkv.view(B, Nc, 2 * HD)
@@ -273,11 +332,10 @@ class CrossAttnBranch(torch.autograd.Function):
                    do.view(B, T, H, D), lse, dq.view(B, T, H, D), dkv3[..., :HD].unflatten(-1, (H, D)),
                    dkv3[..., HD:].unflatten(-1, (H, D)), mask)
         dh = K.gemm_nt(dq, shadow([qw], transpose=True))
-        dqw = K.gemm_tn(dq, h)
+        (dqw,) = wgrad(dq, h, [qw])
         dctx = K.gemm_nt(dkv, shadow([kw, vw], transpose=True))
-        dkvw = K.gemm_tn(dkv, c2)
+        dkw, dvw = wgrad(dkv, c2, [kw, vw])
         dx, dg, db = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2)
-        dkw, dvw = _split_rows(dkvw, [kw, vw])
         return dx.view(B, T, d), dctx.view(B, Nc, d), dg, db, dqw, dkw, dvw, dpw, None
 
 
@@ -322,17 +380,17 @@ class MlpBranch(torch.autograd.Function):
             h = x2
         dy2 = dy.contiguous().view(x2.shape[0], -1)
         ups = [up_w, gate_w] if gated else [up_w]
-        ddown = K.gemm_tn(dy2, g)
+        (ddown,) = wgrad(dy2, g, [down_w])
         ddb = K.colsum(dy2) if has_db else None
         if ctx.fused:   # down-projection dgrad + SwiGLU backward in one kernel; dg is never materialised
             da = K.gemm_nt_dswiglu(dy2, shadow([down_w], transpose=True), a)
             dh = K.gemm_nt(da, shadow_swiglu(up_w, gate_w, transpose=True))
-            dups = _deinterleave_rows(K.gemm_tn(da, h), up_w.shape[0])
+            dups = wgrad(da, h, [up_w, gate_w], swiglu_interleaved=True)
         else:
             dg_ = K.gemm_nt(dy2, shadow([down_w], transpose=True))
             da = K.swiglu_bwd(a, dg_) if gated else K.gelu_bwd(a, dg_)
             dh = K.gemm_nt(da, shadow(ups, transpose=True))
-            dups = _split_rows(K.gemm_tn(da, h), ups)
+            dups = wgrad(da, h, ups)
         dub = K.colsum(da) if has_ub else None
         if ctx.has_ln:
             dx, dgam, dbet = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, kind=nkind, want_beta=has_lnb)

@@ -400,6 +400,14 @@ def copy2d(src: Tensor, dst: Tensor) -> Tensor:
     return dst
 
 
+def add2d_(dst: Tensor, src: Tensor) -> Tensor:
+    """dst += src  (fp32 2-D, row strides allowed)."""
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.shape == src.shape and dst.dim() == 2
+    assert dst.stride(1) == 1 and src.stride(1) == 1
+    call("fk_add2d", src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), dst.shape[0], dst.shape[1], _stream())
+    return dst
+
+
 # ------------------------------------------------------------------------------------------- losses
 def l1_loss_fwd(pred: Tensor, target: Tensor, squared: bool = False, row_weight: Optional[Tensor] = None) -> Tensor:
     """-> loss2 fp32[2] = {mean (weighted) |d| or d^2, weight sum}; row_weight: fp32 [rows] with rows = numel / last dim."""

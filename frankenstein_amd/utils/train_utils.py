@@ -120,6 +120,7 @@ class ParamArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p._fk_arena = True          # engine.wgrad may accumulate weight gradients straight into the arena
         E.bump_weight_epoch()
 
     def rebind_grads(self):
@@ -160,7 +161,8 @@ class GradSync:
         self._works = []
         if self.world > 1:
             for i, p in enumerate(arena.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i]))
+                hook = self._make_hook(self.bucket_of[i])
+                p.register_post_accumulate_grad_hook(hook)     # also fires when engine.wgrad wrote the gradient itself
 
     def _make_hook(self, b: int):
         def hook(_param):
@@ -174,8 +176,16 @@ class GradSync:
     def _launch(self, b: int):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
-        self._works.append(self.dist.all_reduce(self.arena.grad[s:e], op=self.dist.ReduceOp.SUM, group=self.group,
-                                                async_op=True))
+        side = E.wgrad_stream()
+        if side is not None:
+            # the bucket may hold gradients produced on the weight-gradient stream AND on the main stream: order the
+            # collective after both by issuing it from the side stream once that has caught up with the main one
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                w = self.dist.all_reduce(self.arena.grad[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = self.dist.all_reduce(self.arena.grad[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(w)
 
     def finish(self) -> float:
         """Launch whatever has not gone out (unused parameters), wait for all buckets; returns the factor that turns
@@ -184,8 +194,13 @@ class GradSync:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)
+            side = E.wgrad_stream()
             for w in self._works:
-                w.wait()
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        w.wait()
+                else:
+                    w.wait()
         self._works.clear()
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
@@ -197,8 +212,11 @@ class FusedAdamW:
     every parameter, utils/train_utils.py:117-119) + clip_grad_value_ (:142), as one kernel over the arena."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999),
-                 eps: float = 1e-8, grad_clip: Optional[float] = None, group=None, bucket_bytes: int = 64 << 20):
+                 eps: float = 1e-8, grad_clip: Optional[float] = None, group=None, bucket_bytes: int = 64 << 20,
+                 overlap_wgrad: bool = True):
         self.arena = ParamArena(model)
+        if overlap_wgrad and self.arena.flat.is_cuda and E.wgrad_stream() is None:
+            E.enable_wgrad_stream(True)
         self.m = torch.zeros_like(self.arena.flat)
         self.v = torch.zeros_like(self.arena.flat)
         self.param_groups = [dict(params=self.arena.params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)]
@@ -214,6 +232,9 @@ class FusedAdamW:
         g = self.param_groups[0]
         self.arena.rebind_grads()
         scale = self.sync.finish()
+        side = E.wgrad_stream()
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)      # join the weight-gradient stream before the update
         self.t += 1
         K.adamw_step_(self.arena.flat, self.arena.grad, self.m, self.v, self.t, g['lr'], g['betas'][0], g['betas'][1],
                       g['eps'], g['weight_decay'], clip=self.grad_clip or 0.0, grad_scale=scale, zero_grad=True)

@@ -147,6 +147,9 @@ int fk_prefix_mask(const int64_t* q_ids, const int64_t* k_ids, int64_t block, in
 /* 2-D strided copy (same dtype): dst[r*ldd + c] = src[r*lds + c]. */
 int fk_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype, void* stream);
 
+/* dst[r, c] += src[r, c] (fp32, strided): accumulates a weight-gradient slab into the flat gradient arena. */
+int fk_add2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream);
+
 /* ---- GPT input embedding (models/gpt2_model.py:183-196): out[b, t, :] = (t < t_ctx ? prefix[b, t, :]
  *      : wte[idx[b, t - t_ctx], :]) + wpe[t, :];  wte/wpe are the fp32 master tables, prefix/out have `dtype`.
  *      Backward of the wte gather: dwte[idx[b, j], :] += dout[b, t_ctx + j, :] (fp32 atomics; dwte is the same

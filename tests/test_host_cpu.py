@@ -140,3 +140,30 @@ def test_reference_import_names_resolve(monkeypatch):
     from models.gpt2_model import GPT, GPTConfig  # noqa: F401
     from utils.train_utils import TrainConfig, run_train_model, count_parameters, simple_train_model, train_step  # noqa: F401
     assert frankenstein_amd.compute_dtype() == torch.bfloat16
+
+
+def test_post_accumulate_hook_fires_for_directly_written_grads():
+    """engine.wgrad accumulates weight gradients itself and hands autograd None; GradSync's bucket readiness relies on
+    the parameter's post-accumulate-grad hook still running (once, after the last use of the weight)."""
+    import torch
+
+    class Direct(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            w.grad.add_(dy.t() @ x)
+            return dy @ w, None
+
+    w = torch.nn.Parameter(torch.randn(3, 4))
+    w.grad = torch.zeros_like(w)
+    fired = []
+    w.register_post_accumulate_grad_hook(lambda p: fired.append(p.grad.clone()))
+    x = torch.randn(5, 4, requires_grad=True)
+    (Direct.apply(Direct.apply(x, w)[:, :3] @ torch.randn(3, 4), w)).sum().backward()      # weight used twice
+    assert len(fired) == 1
+    assert torch.equal(fired[0], w.grad) and w.grad.abs().sum() > 0
