@@ -20,6 +20,9 @@
 
 namespace {
 
+#ifndef FK_EPI_UNROLL
+#define FK_EPI_UNROLL 1   // the sweep is executed once per tile: unrolled it is ~40 KiB of straight-line code per kernel and the
+#endif                    // instruction fetch (not VALU, LDS or HBM) bounds the epilogue; rolled it stays in the instruction cache
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 constexpr int ROW_BYTES = 128;                 // NT image: bytes per k-tile row
 constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand tile
@@ -54,15 +57,21 @@ struct NtArgs {
   const float* rope_table; int64_t rope_bs; int rope_T, rope_off, rope_D, rope_cols;
 };
 
+// sigmoid: the throughput (bf16) mode uses the hardware reciprocal (1 ulp), the fp32 parity mode an exact division
+template <typename T> FK_DEV float sigmoid_f(float x) {
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+  else return 1.0f / (1.0f + __expf(-x));
+}
+
 // Epilogue shared by the NT kernels: acc are C^T tiles (lane = output row m, registers = 4 consecutive n).
-template <typename T, typename TO>
+template <typename T, typename TO, bool VEC_ONLY = false>
 FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mrow0, int ncol0, int lane, bool sync) {
   // acc = one wave's 64x64 sub-tile whose top-left output element is (mrow0, ncol0); stg = that wave's 16 KiB of LDS
   const int li = lane & 31, lh = lane >> 5;
   const T* bias = (const T*)p.bias;
   const T* res = (const T*)p.res;
   TO* C = (TO*)p.C;
-  if (p.vec_epi) {
+  if (VEC_ONLY || p.vec_epi) {
     // Vector epilogue: accumulators are C^T tiles (lane = output row m, registers = 4 consecutive n), staged as
     // fp32 through this wave's 16 KiB slice of the (now idle) LDS tile buffers, then swept row-wise so every
     // global access is a full 16-byte-per-lane coalesced row segment; bias / residual added in fp32, one rounding.
@@ -79,34 +88,53 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mro
           f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
           *reinterpret_cast<f32x4*>(stg + eoff(i * 32 + li, j * 32 + 8 * g + 4 * lh)) = v;
         }
+    // The sweep is VALU-bound (a wave64 VALU op holds the SIMD for 4 cycles and no MFMA runs beside it), so everything
+    // row- or column-invariant is hoisted: one division per sub-tile, pointer increments per pass, uniform branches
+    // around absent bias / residual / RoPE work, and the bf16 mode uses v_rcp_f32 for the sigmoid.
     const int col = (lane & 7) * 8, nb = ncol0 + col;
     const bool col_ok = nb < p.N;                   // N % 8 == 0 on this path
+    const int r0 = lane >> 3, mb = mrow0 + r0;      // this lane's row in pass 0; pass ps handles row mb + 8 * ps
     float bv[8];
+    if (bias && col_ok) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (bias && col_ok) ? to_f32<T>(bias[nb + e]) : 0.0f;
-#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = to_f32<T>(bias[nb + e]);
+    }
+    // residual row of pass 0 (periodic residual: row m % res_rows, advanced by 8 per pass with wrap)
+    int rr = 0;
+    if (res) rr = p.res_rows > 0 ? mb % (int)p.res_rows : mb;
+    // RoPE: (cos, sin) pairs of token (m % T) of sample (m / T) for the 4 complex pairs of this lane's 8 columns
+    const float* tb = nullptr;
+    int tt = 0;
+    const bool do_rope = p.rope_table && nb < p.rope_cols && col_ok;
+    if (do_rope) {
+      tt = mb % p.rope_T;
+      const int bb = mb / p.rope_T, dd = nb % p.rope_D;
+      tb = p.rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
+    }
+#pragma unroll FK_EPI_UNROLL
     for (int ps = 0; ps < 8; ++ps) {
-      const int row = ps * 8 + (lane >> 3), m = mrow0 + row;
+      const int row = ps * 8 + r0, m = mrow0 + row;
       f32x4 a = *reinterpret_cast<const f32x4*>(stg + eoff(row, col));
       f32x4 b = *reinterpret_cast<const f32x4*>(stg + eoff(row, col + 4));
       if (m < p.M && col_ok) {
-        float v[8] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3], b[0] + bv[4], b[1] + bv[5], b[2] + bv[6], b[3] + bv[7]};
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        }
         if (res) {
-          const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
-          const T* rp = res + rr * p.ldr + nb;
+          const T* rp = res + (int64_t)rr * p.ldr + nb;
           if constexpr (sizeof(T) == 2) {
             bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rp);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
           } else {
-            f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+            f32x4 q0 = *reinterpret_cast<const f32x4*>(rp), q1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
           }
         }
-        if (p.rope_table && nb < p.rope_cols) {
-          const int tt = m % p.rope_T, bb = m / p.rope_T, dd = nb % p.rope_D;
-          const float* tb = p.rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
+        if (do_rope) {
           const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 4);
           const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #pragma unroll
@@ -140,9 +168,9 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mro
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float a1 = hv[8 * gq + e], a3 = hv[8 * gq + 4 + e], dg = v[4 * gq + e];
-                const float sg = 1.0f / (1.0f + __expf(-a1));
-                ov[8 * gq + e] = dg * a3 * sg * (1.0f + a1 * (1.0f - sg));
-                ov[8 * gq + 4 + e] = dg * a1 * sg;
+                const float sg = sigmoid_f<T>(a1), ds = dg * sg;
+                ov[8 * gq + e] = ds * a3 * (1.0f + a1 * (1.0f - sg));
+                ov[8 * gq + 4 + e] = ds * a1;
               }
             if constexpr (sizeof(T) == 2) {
               bf16x8 o0, o1;
@@ -156,40 +184,51 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mro
                 *reinterpret_cast<f32x4*>(dp + 4 * q4) = f32x4{ov[4 * q4], ov[4 * q4 + 1], ov[4 * q4 + 2], ov[4 * q4 + 3]};
             }
           }
-          continue;
-        }
-        TO* cp = C + (int64_t)m * p.ldc + nb;
-        if constexpr (sizeof(TO) == 2) {
-          bf16x8 o8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x8*>(cp) = o8;
         } else {
-          *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        }
-        if (p.mode == 1) {
-          // SwiGLU forward fused into the up-projection: the 8 columns are (h1[4], h3[4]) of 4 hidden units
-          if constexpr (sizeof(TO) == sizeof(T)) {
-            T* gp = (T*)p.aux + (int64_t)m * p.ldaux + (nb >> 1);
-            float gq[4];
+          TO* cp = C + (int64_t)m * p.ldc + nb;
+          if constexpr (sizeof(TO) == 2) {
+            bf16x8 o8;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gq[e] = v[e] / (1.0f + __expf(-v[e])) * v[4 + e];
-            if constexpr (sizeof(T) == 2) {
-              bf16x4 g4;
+            for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x8*>(cp) = o8;
+          } else {
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+          if (p.mode == 1) {
+            // SwiGLU forward fused into the up-projection: the 8 columns are (h1[4], h3[4]) of 4 hidden units
+            if constexpr (sizeof(TO) == sizeof(T)) {
+              T* gp = (T*)p.aux + (int64_t)m * p.ldaux + (nb >> 1);
+              float gq[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) g4[e] = (bf16_t)gq[e];
-              *reinterpret_cast<bf16x4*>(gp) = g4;
-            } else {
-              *reinterpret_cast<f32x4*>(gp) = f32x4{gq[0], gq[1], gq[2], gq[3]};
+              for (int e = 0; e < 4; ++e) gq[e] = v[e] * sigmoid_f<T>(v[e]) * v[4 + e];
+              if constexpr (sizeof(T) == 2) {
+                bf16x4 g4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g4[e] = (bf16_t)gq[e];
+                *reinterpret_cast<bf16x4*>(gp) = g4;
+              } else {
+                *reinterpret_cast<f32x4*>(gp) = f32x4{gq[0], gq[1], gq[2], gq[3]};
+              }
             }
           }
         }
+      }
+      // advance the row-dependent cursors by 8 rows
+      if (res) {
+        rr += 8;
+        if (p.res_rows > 0) { while (rr >= (int)p.res_rows) rr -= (int)p.res_rows; }
+      }
+      if (do_rope) {
+        tt += 8;
+        tb += 8 * p.rope_D;
+        while (tt >= p.rope_T) { tt -= p.rope_T; tb += p.rope_bs - (int64_t)p.rope_T * p.rope_D; }
       }
     }
     return;
   }
   // scalar epilogue (any N / ldc): lane = output row m, registers = columns n
+  if constexpr (!VEC_ONLY) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = mrow0 + i * 32 + li;
@@ -206,6 +245,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mro
         C[(int64_t)m * p.ldc + n] = from_f32<TO>(v);
       }
     }
+  }
   }
 }
 
@@ -431,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
 #pragma unroll
     for (int hh = 0; hh < MT / 2; ++hh) {
       f32x16 (&sub)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * hh][0]);
-      nt_epilogue<T, TO>(p, sub, smem + wave * 16384, m0 + wm * WM + hh * 64, n0 + wn * 64, lane, false);
+      nt_epilogue<T, TO, true>(p, sub, smem + wave * 16384, m0 + wm * WM + hh * 64, n0 + wn * 64, lane, false);
     }
     __syncthreads();
   }
@@ -571,6 +611,150 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs p) {
   }
 }
 
+// Large-tile weight-gradient kernel (bf16): 384 (A columns) x 128 (B columns) output tile per 8-wave block, 64 rows of m per
+// stage, both operands brought in by LDS-DMA (a 64 KiB stage, double buffered, one block per CU).  Why not the 128x128
+// register-staged kernel above: its m-loop runs one 0.3 us k-tile ahead of loads that take 1-3 us, and every staged byte pays
+// the ~79 B/clk ds_write path; here a stage carries 2 x 24 MFMAs per SIMD (~1 us) and nothing goes through ds_write.
+// Images are [64 m][row bytes] (A 768 B, B 256 B) with the 64-B granule swizzle of tn_off_bf16 inside every 256-B group,
+// applied on the DMA *source* column (the LDS side of an LDS-DMA is lane-linear).  Wave w: rows 96*(w>>1) of the tile's A
+// columns (3 MFMA tiles) x columns 64*(w&1) (2 tiles).  Requires M % 64 == 0, N1 % 384 == 0, N2 % 128 == 0.
+constexpr int TG_A = 384, TG_B = 128, TG_K = 64;
+constexpr int TG_A_ROW = TG_A * 2, TG_B_ROW = TG_B * 2;
+constexpr int TG_A_BYTES = TG_K * TG_A_ROW, TG_B_BYTES = TG_K * TG_B_ROW, TG_STAGE = TG_A_BYTES + TG_B_BYTES;   // 48 + 16 KiB
+
+template <int PITCH> FK_DEV int tg_off(int row, int bytecol) {
+  return row * PITCH + (bytecol & ~255) + ((((bytecol >> 6) ^ row) & 3) << 6) + (bytecol & 63);
+}
+// ds_read_b64_tr_b16 as inline asm: hipcc orders the builtin form behind every pending LDS-DMA (s_waitcnt vmcnt(0) in front
+// of the first fragment read of a k-tile), which serialises the prefetch with the MFMAs.  The asm form is invisible to that
+// pass, so LDS completion is counted by hand (lgkm_wait) and DMA completion by the __syncthreads() that ends each k-tile.
+template <int OFF> FK_DEV bf16x4 tr_read(unsigned base) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(base), "n"(OFF) : "memory");
+  return __builtin_bit_cast(bf16x4, r);
+}
+template <int N> FK_DEV void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);      // hipcc may otherwise hoist register-only MFMAs above the wait
+}
+template <int PITCH, int S> FK_DEV void tg_frag(Frag<bf16_t>& f, unsigned base) {
+  const bf16x4 v0 = tr_read<(16 * S) * PITCH>(base), v1 = tr_read<(16 * S + 4) * PITCH>(base);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f.v[e] = v0[e]; f.v[4 + e] = v1[e]; }
+}
+FK_DEV unsigned lds_addr(const char* p) {
+  return (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) const char*)p);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int nt2 = p.N2 / TG_B, ntiles = (p.N1 / TG_A) * nt2;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = (int)(L / ntiles), tile = (int)(L % ntiles);
+  const int a0 = (tile / nt2) * TG_A, b0 = (tile % nt2) * TG_B;
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+  const int nk = (mend - mbeg) / TG_K;
+
+  // per-lane DMA sources: piece q of an image = LDS bytes [1024 q, 1024 q + 1024), lane l -> 16 B at 1024 q + 16 l
+  const T* srcA[6];
+  const T* srcB[2];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int o = (wave * 6 + j) * 1024 + lane * 16, row = o / TG_A_ROW, bc = o % TG_A_ROW;
+    const int sc = (bc & ~255) + ((((bc >> 6) ^ row) & 3) << 6) + (bc & 63);
+    srcA[j] = (const T*)p.A + (int64_t)(mbeg + row) * p.lda + a0 + sc / 2;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int o = (wave * 2 + j) * 1024 + lane * 16, row = o / TG_B_ROW, bc = o % TG_B_ROW;
+    const int sc = ((((bc >> 6) ^ row) & 3) << 6) + (bc & 63);
+    srcB[j] = (const T*)p.B + (int64_t)(mbeg + row) * p.ldb + b0 + sc / 2;
+  }
+  const int64_t astep = (int64_t)TG_K * p.lda, bstep = (int64_t)TG_K * p.ldb;
+  auto stage = [&](int buf) {
+    char* as = smem + buf * TG_STAGE;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)srcA[j], (lds_void_t*)(as + (wave * 6 + j) * 1024), 16, 0, 0);
+      srcA[j] += astep;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)srcB[j], (lds_void_t*)(as + TG_A_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
+      srcB[j] += bstep;
+    }
+  };
+
+  // fragment read bases (stage 0): lane (g = lane>>4, i = lane&15) reads row 8*(g>>1) + (i>>2) (+16 s + 4 t by immediate offset)
+  unsigned fbase[5];
+  {
+    const int g = lane >> 4, i = lane & 15, row = 8 * (g >> 1) + (i >> 2), dc = 16 * (g & 1) + 4 * (i & 3);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fbase[q] = lds_addr(smem) + tg_off<TG_A_ROW>(row, (wm * 96 + q * 32 + dc) * 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fbase[3 + q] = lds_addr(smem) + TG_A_BYTES + tg_off<TG_B_ROW>(row, (wn * 64 + q * 32 + dc) * 2);
+  }
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (nk > 0) stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage((kt + 1) & 1);
+    const unsigned bo = (kt & 1) * TG_STAGE;
+    Frag<T> f0[5], f1[5];
+#define TG_LOAD(F, S)                                                      \
+    tg_frag<TG_A_ROW, S>(F[0], fbase[0] + bo); tg_frag<TG_A_ROW, S>(F[1], fbase[1] + bo); \
+    tg_frag<TG_A_ROW, S>(F[2], fbase[2] + bo); tg_frag<TG_B_ROW, S>(F[3], fbase[3] + bo); \
+    tg_frag<TG_B_ROW, S>(F[4], fbase[4] + bo);
+#define TG_MMA(F)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i)                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], F[i], F[3 + j]);
+    TG_LOAD(f0, 0)
+    TG_LOAD(f1, 1)
+    lgkm_wait<10>();
+    TG_MMA(f0)
+    TG_LOAD(f0, 2)
+    lgkm_wait<10>();
+    TG_MMA(f1)
+    TG_LOAD(f1, 3)
+    lgkm_wait<10>();
+    TG_MMA(f0)
+    lgkm_wait<0>();
+    TG_MMA(f1)
+#undef TG_LOAD
+#undef TG_MMA
+    __syncthreads();
+  }
+
+  float* out = (p.nsplit > 1) ? p.ws + (int64_t)split * p.N1 * p.N2 : p.C;
+  const int64_t ldo = (p.nsplit > 1) ? p.N2 : p.ldc;
+  const bool accum = (p.nsplit == 1) && p.accumulate;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = b0 + wn * 64 + j * 32 + li;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = a0 + wm * 96 + i * 32 + acc_row(r, lh);
+        float* dst = out + (int64_t)m * ldo + n;
+        *dst = accum ? (*dst + acc[i][j][r]) : acc[i][j][r];
+      }
+  }
+}
+
 __global__ void reduce_slabs_kernel(const float* ws, float* C, int64_t ldc, int N1, int N2, int nsplit, int accumulate) {
   const int64_t total = (int64_t)N1 * N2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -605,6 +789,18 @@ int tn_splits(int64_t M, int64_t N1, int64_t N2, int bkm) {
   int64_t want = fk_cdiv(1024, tiles);                     // ~4 blocks per CU
   const int64_t maxs = fk_cdiv(M, (int64_t)bkm * 4);        // >= 4 k-tiles per split
   if (want >= 8) want = (want + 7) / 8 * 8;                 // whole splits per XCD
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+// large-tile TN path: bf16, M % 64 == 0, N1 % 384 == 0, N2 % 128 == 0 and enough rows to be worth one block per CU
+bool tn_big_ok(int64_t M, int64_t N1, int64_t N2, int dtype) {
+  return dtype == FK_BF16 && M % TG_K == 0 && M >= 16384 && N1 % TG_A == 0 && N2 % TG_B == 0;
+}
+int tn_big_splits(int64_t M, int64_t N1, int64_t N2) {
+  const int64_t tiles = (N1 / TG_A) * (N2 / TG_B);
+  int64_t want = 256 / tiles;                               // one wave of blocks, one block per CU
+  const int64_t maxs = M / (TG_K * 8);                      // >= 8 k-tiles per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   return (int)want;
@@ -710,7 +906,7 @@ int fk_gemm_nt_dswiglu(const void* dY, int64_t lda, const void* W2T, int64_t ldb
 }
 
 size_t fk_gemm_tn_workspace_bytes(int64_t M, int64_t N1, int64_t N2, int dtype) {
-  const int ns = tn_splits(M, N1, N2, dtype == FK_BF16 ? 64 : 32);
+  const int ns = tn_big_ok(M, N1, N2, dtype) ? tn_big_splits(M, N1, N2) : tn_splits(M, N1, N2, dtype == FK_BF16 ? 64 : 32);
   return ns > 1 ? (size_t)ns * N1 * N2 * sizeof(float) : 0;
 }
 
@@ -723,14 +919,20 @@ int fk_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
   FK_CHECK_ARG(N1 % vec == 0 && N2 % vec == 0 && lda % vec == 0 && ldb % vec == 0,
                "fk_gemm_tn: N1/N2/lda/ldb must be multiples of %d (N1=%lld N2=%lld)", vec, (long long)N1, (long long)N2);
   FK_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "fk_gemm_tn: A/B must be 16-byte aligned");
-  const int ns = tn_splits(M, N1, N2, bkm);
+  const bool big = tn_big_ok(M, N1, N2, dtype);
+  const int ns = big ? tn_big_splits(M, N1, N2) : tn_splits(M, N1, N2, bkm);
   const size_t need = ns > 1 ? (size_t)ns * N1 * N2 * sizeof(float) : 0;
   FK_CHECK_ARG(workspace_bytes >= need && (need == 0 || workspace), "fk_gemm_tn: workspace too small (%zu < %zu)", workspace_bytes, need);
   int64_t rps = fk_cdiv(fk_cdiv(M, ns), bkm) * bkm;
   TnArgs p{A, B, C, (float*)workspace, lda, ldb, ldc, (int)M, (int)N1, (int)N2, (int)rps, ns, accumulate};
   dim3 grid((unsigned)(fk_cdiv(N1, BM) * fk_cdiv(N2, BN) * ns)), block(NTHREADS);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 4 * TILE_BYTES, s, p);
+  if (big) {
+    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TG_STAGE) == hipSuccess);
+    (void)once;
+    dim3 bgrid((unsigned)((N1 / TG_A) * (N2 / TG_B) * ns));
+    hipLaunchKernelGGL(gemm_tn_big_kernel, bgrid, dim3(512), 2 * TG_STAGE, s, p);
+  } else if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 4 * TILE_BYTES, s, p);
   else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 4 * TILE_BYTES, s, p);
   FK_CHECK_LAUNCH("fk_gemm_tn");
   if (ns > 1) {

@@ -139,7 +139,7 @@ class GradSync:
     1/world is folded into the optimizer kernel) as soon as every parameter of the bucket has its gradient,
     asynchronously on the process group's communication stream, so the exchange overlaps the remaining backward."""
 
-    def __init__(self, arena: ParamArena, group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, arena: ParamArena, group=None, bucket_bytes: int = 8 << 20):
         import torch.distributed as dist
         self.dist, self.group, self.arena = dist, group, arena
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -212,7 +212,7 @@ class FusedAdamW:
     every parameter, utils/train_utils.py:117-119) + clip_grad_value_ (:142), as one kernel over the arena."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999),
-                 eps: float = 1e-8, grad_clip: Optional[float] = None, group=None, bucket_bytes: int = 64 << 20,
+                 eps: float = 1e-8, grad_clip: Optional[float] = None, group=None, bucket_bytes: int = 8 << 20,
                  overlap_wgrad: bool = True):
         self.arena = ParamArena(model)
         if overlap_wgrad and self.arena.flat.is_cuda and E.wgrad_stream() is None:

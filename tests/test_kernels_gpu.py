@@ -108,6 +108,27 @@ def test_gemm_tn(K, dtype, shape):
     close(acc, ref + 1, torch.float32, atol32=2e-3 if dtype == torch.float32 else 5e-2 * math.sqrt(M / 1000), rtol32=1e-4 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("shape", [(16384 + 192, 384, 256), (24576, 768, 128), (16384, 384, 384)])
+def test_gemm_tn_large_tile_exact_integers(K, shape):
+    """the 384x128-tile LDS-DMA weight-gradient kernel (bf16, M % 64 == 0, N1 % 384 == 0, N2 % 128 == 0): asymmetric integer
+    operands make the result exact, so any fragment / swizzle / split mix-up shows up as a hard mismatch; strided views too."""
+    M, N1, N2 = shape
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-2, 3, (M, N1 + 8), generator=g).float()
+    b = torch.randint(-2, 3, (M, N2), generator=g).float()
+    a[:, 3] += (torch.arange(M) % 5).float()
+    b[:, 1] += (torch.arange(M) % 3).float()
+    ad = dev(a, torch.bfloat16)[:, :N1]                     # row stride N1 + 8
+    bd = dev(b, torch.bfloat16)
+    ref = (a[:, :N1].double().t() @ b.double()).float()
+    assert float(ref.abs().max()) < 2 ** 24
+    got = K.gemm_tn(ad, bd)
+    assert torch.equal(got.cpu(), ref)
+    acc = torch.full((N1, N2), 3.0, device="cuda")
+    K.gemm_tn(ad, bd, out=acc, accumulate=True)
+    assert torch.equal(acc.cpu(), ref + 3)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_colsum(K, dtype):
     x = rnd(5000, 200, seed=3)
