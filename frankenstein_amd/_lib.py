@@ -8,7 +8,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libfranken_hip.so"
+import os
+
+# FRANKEN_HIP_LIB selects another build of the same ABI (A/B timing of kernel variants on one GPU box)
+LIB_PATH = Path(os.environ.get("FRANKEN_HIP_LIB") or Path(__file__).resolve().parent / "libfranken_hip.so")
 
 FK_F32, FK_BF16 = 0, 1
 MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL, MASK_PREFIX, MASK_KEYPAD = 0, 1, 2, 3, 4

@@ -68,19 +68,20 @@ def _arena_grad(p: Tensor):
 
 def wgrad(a: Tensor, b: Tensor, params: Sequence[Tensor], swiglu_interleaved: bool = False):
     """Gradients of the row-concatenated weights `params` = a^T b ([sum N, K], fp32).  Returns a list aligned with params:
-    tensors (caller hands them to autograd) or Nones when the result was accumulated directly into the arena."""
+    tensors (caller hands them to autograd) or Nones when the result was accumulated directly into the arena (on the
+    weight-gradient stream when one is enabled, else on the current stream)."""
     side = _WGRAD_STREAM
     grads = [_arena_grad(p) for p in params]
-    if side is None or any(g is None for g in grads):
+    if any(g is None for g in grads):
         dw = K.gemm_tn(a, b)
         if swiglu_interleaved:
             return list(_deinterleave_rows(dw, params[0].shape[0]))
         return _split_rows(dw, params)
-    main = torch.cuda.current_stream()
-    side.wait_stream(main)
-    a.record_stream(side)
-    b.record_stream(side)
-    with torch.cuda.stream(side):
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+        a.record_stream(side)
+        b.record_stream(side)
+    with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
         Kd = b.shape[1]
         adjacent = all(grads[i + 1].data_ptr() == grads[i].data_ptr() + grads[i].numel() * 4 for i in range(len(grads) - 1))
         if swiglu_interleaved:

@@ -215,7 +215,7 @@ class FusedAdamW:
                  eps: float = 1e-8, grad_clip: Optional[float] = None, group=None, bucket_bytes: int = 8 << 20,
                  overlap_wgrad: bool = True):
         self.arena = ParamArena(model)
-        if overlap_wgrad and self.arena.flat.is_cuda and E.wgrad_stream() is None:
+        if overlap_wgrad and os.environ.get("FK_WGRAD_STREAM", "1") != "0" and self.arena.flat.is_cuda and E.wgrad_stream() is None:
             E.enable_wgrad_stream(True)
         self.m = torch.zeros_like(self.arena.flat)
         self.v = torch.zeros_like(self.arena.flat)
