@@ -44,6 +44,7 @@ SIGNATURES = {
     "fk_gelu_bwd": (_int, [_p, _p, _p, _i64, _int, _p]),
     "fk_cast_pack": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _int, _p]),
     "fk_cast_pack_rows": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _i64, _i64, _i64, _int, _p]),
+    "fk_cast_pack_multi": (_int, [_p, _i64, _i64, _int, _p]),
     "fk_cast": (_int, [_p, _int, _p, _int, _i64, _p]),
     "fk_add": (_int, [_p, _p, _p, _i64, _int, _p]),
     "fk_gather_rows": (_int, [_p, _i64, _int, _p, _i64, _p, _i64, _int, _i64, _i64, _i64, _int, _p]),

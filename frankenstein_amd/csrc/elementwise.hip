@@ -175,6 +175,33 @@ __global__ void cast_pack_kernel(const float* src, int64_t lds, T* dst, int64_t 
     else dst[(int64_t)rd * ldd + c] = from_f32<T>(v);
   }
 }
+// all shadow re-packs of a step in one launch: a block takes 1024-element chunks, finds the owning job by a (block-uniform)
+// binary search over chunk_begin and then does what cast_pack_kernel does
+template <typename T>
+__global__ void cast_pack_multi_kernel(const fk_pack_job* jobs, int njobs, int64_t total_chunks) {
+  for (int64_t ch = blockIdx.x; ch < total_chunks; ch += gridDim.x) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].chunk_begin <= ch) lo = mid; else hi = mid - 1;
+    }
+    const fk_pack_job jb = jobs[lo];
+    const int64_t total = (int64_t)jb.rows * jb.cols, base = (ch - jb.chunk_begin) * 1024;
+    T* dst = (T*)jb.dst;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t i = base + q * 256 + threadIdx.x;
+      if (i >= total) break;
+      int r, c;
+      if (jb.transpose) { r = (int)(i % jb.rows); c = (int)(i / jb.rows); }
+      else { r = (int)(i / jb.cols); c = (int)(i % jb.cols); }
+      const int rd = jb.rblk > 0 ? (r / jb.rblk) * jb.rstride + (r % jb.rblk) + jb.roff : r;
+      const float v = jb.src[(int64_t)r * jb.lds + c];
+      if (jb.transpose) dst[(int64_t)c * jb.ldd + rd] = from_f32<T>(v);
+      else dst[(int64_t)rd * jb.ldd + c] = from_f32<T>(v);
+    }
+  }
+}
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* src, TD* dst, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -381,6 +408,17 @@ int fk_cast_pack_rows(const float* src, int64_t lds, void* dst, int64_t ldd, int
 int fk_cast_pack(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
                  int dtype, void* stream) {
   return fk_cast_pack_rows(src, lds, dst, ldd, rows, cols, transpose, 0, 0, 0, dtype, stream);
+}
+int fk_cast_pack_multi(const fk_pack_job* jobs, int64_t njobs, int64_t total_chunks, int dtype, void* stream) {
+  FK_DT_CHECK("fk_cast_pack_multi");
+  FK_CHECK_ARG(jobs && njobs > 0 && njobs < (1LL << 31) && total_chunks > 0, "fk_cast_pack_multi: bad arguments");
+  static_assert(TPB == 256, "a chunk is 4 x 256 elements");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned nb = (unsigned)(total_chunks < 8192 ? total_chunks : 8192);
+  if (dtype == FK_BF16) hipLaunchKernelGGL(cast_pack_multi_kernel<bf16_t>, dim3(nb), dim3(TPB), 0, s, jobs, (int)njobs, total_chunks);
+  else hipLaunchKernelGGL(cast_pack_multi_kernel<float>, dim3(nb), dim3(TPB), 0, s, jobs, (int)njobs, total_chunks);
+  FK_CHECK_LAUNCH("fk_cast_pack_multi");
+  return FK_OK;
 }
 int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
   FK_CHECK_ARG((src_dtype == FK_F32 || src_dtype == FK_BF16) && (dst_dtype == FK_F32 || dst_dtype == FK_BF16), "fk_cast: bad dtype");

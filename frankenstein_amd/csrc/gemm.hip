@@ -64,9 +64,9 @@ template <typename T> FK_DEV float sigmoid_f(float x) {
 }
 
 // Epilogue shared by the NT kernels: acc are C^T tiles (lane = output row m, registers = 4 consecutive n).
-template <typename T, typename TO, bool VEC_ONLY = false>
-FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mrow0, int ncol0, int lane, bool sync) {
-  // acc = one wave's 64x64 sub-tile whose top-left output element is (mrow0, ncol0); stg = that wave's 16 KiB of LDS
+template <typename T, typename TO, bool VEC_ONLY = false, int NI = 2>
+FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mrow0, int ncol0, int lane, bool sync) {
+  // acc = one wave's (32 NI) x 64 sub-tile whose top-left output element is (mrow0, ncol0); stg = that wave's 8 NI KiB of LDS
   const int li = lane & 31, lh = lane >> 5;
   const T* bias = (const T*)p.bias;
   const T* res = (const T*)p.res;
@@ -80,7 +80,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mro
     auto eoff = [](int row, int colf) { return row * 256 + ((((colf >> 2) ^ (row & 15)) << 4) | ((colf & 3) << 2)); };
     if (sync) __syncthreads();                      // all waves finished reading the operand tiles
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -112,7 +112,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mro
       tb = p.rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
     }
 #pragma unroll FK_EPI_UNROLL
-    for (int ps = 0; ps < 8; ++ps) {
+    for (int ps = 0; ps < 4 * NI; ++ps) {
       const int row = ps * 8 + r0, m = mrow0 + row;
       f32x4 a = *reinterpret_cast<const f32x4*>(stg + eoff(row, col));
       f32x4 b = *reinterpret_cast<const f32x4*>(stg + eoff(row, col + 4));
@@ -230,7 +230,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[2][2], char* stg, int mro
   // scalar epilogue (any N / ldc): lane = output row m, registers = columns n
   if constexpr (!VEC_ONLY) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int m = mrow0 + i * 32 + li;
     if (m >= p.M) continue;
     const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
@@ -342,7 +342,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(NtArgs p) {
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
   const int t_beg = xcd * q8 + min(xcd, r8), t_end = t_beg + q8 + (xcd < r8 ? 1 : 0);
 
-  for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
+  const T* srcA[4];
+  const T* srcB[4];
+  auto set_src = [&](int tile) {
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (wave * 4 + j) * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
+      srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ch * 8;
+    }
+  };
+  auto stage = [&](int buf, int k0) {
+    char* as = smem + buf * 2 * TILE_BYTES + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + TILE_BYTES + j * 1024), 16, 0, 0);
+    }
+  };
+  const int nk = p.K / 64;
+  int tile = t_beg + jb;
+  if (tile < t_end) { set_src(tile); stage(0, 0); }
+  for (; tile < t_end; tile += nbx) {
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     f32x16 acc[2][2];
 #pragma unroll
@@ -351,27 +374,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(NtArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const T* srcA[4];
-    const T* srcB[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (wave * 4 + j) * 8 + (lane >> 3);
-      const int ch = (lane & 7) ^ ((row >> 1) & 7);
-      srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
-      srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ch * 8;
-    }
-    auto stage = [&](int buf, int k0) {
-      char* as = smem + buf * 2 * TILE_BYTES + wave * 4096;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + j * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + TILE_BYTES + j * 1024), 16, 0, 0);
-      }
-    };
-    const int nk = p.K / 64;
-    stage(0, 0);
-    __syncthreads();
+    __syncthreads();     // this tile's first k-stage has landed (vmcnt(0)); every wave is done with the previous tile's staging
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * 64);
       const char* as = smem + (kt & 1) * 2 * TILE_BYTES;
@@ -390,8 +393,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(NtArgs p) {
       }
       __syncthreads();   // drains this wave's LDS-DMA (vmcnt) and orders every wave's reads / DMA writes
     }
-    nt_epilogue<T, TO>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane, true);
-    __syncthreads();     // epilogue staging region is reused by the next tile's operand DMA
+    // Both buffers are idle: the next tile's first k-stage goes into buffer 0 now, so its DMA latency (and this tile's store
+    // drain) run under the epilogue, which stages its two 32-row halves through this wave's 8 KiB slice of buffer 1.
+    if (tile + nbx < t_end) { set_src(tile + nbx); stage(0, 0); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
+      nt_epilogue<T, TO, false, 1>(p, sub, smem + 2 * TILE_BYTES + wave * 8192, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, false);
+    }
   }
 }
 
@@ -415,18 +424,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
   const int t_beg = xcd * q8 + min(xcd, r8), t_end = t_beg + q8 + (xcd < r8 ? 1 : 0);
 
-  for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
+  static_assert(STAGE >= 8 * 8192, "the epilogue stages 8 waves x 8 KiB through the second stage buffer");
+  const T* srcA[A_PER_WAVE];
+  const T* srcB[B_PER_WAVE];
+  auto set_src = [&](int tile) {
     const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const T* srcA[A_PER_WAVE];
-    const T* srcB[B_PER_WAVE];
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) {
       const int row = (wave * A_PER_WAVE + j) * 8 + (lane >> 3);
@@ -437,18 +439,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
       const int row = (wave * B_PER_WAVE + j) * 8 + (lane >> 3);
       srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
     }
-    auto stage = [&](int buf, int k0) {
-      char* as = smem + buf * STAGE;
+  };
+  auto stage = [&](int buf, int k0) {
+    char* as = smem + buf * STAGE;
 #pragma unroll
-      for (int j = 0; j < A_PER_WAVE; ++j)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + (wave * A_PER_WAVE + j) * 1024), 16, 0, 0);
+    for (int j = 0; j < A_PER_WAVE; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + (wave * A_PER_WAVE + j) * 1024), 16, 0, 0);
 #pragma unroll
-      for (int j = 0; j < B_PER_WAVE; ++j)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + A_BYTES + (wave * B_PER_WAVE + j) * 1024), 16, 0, 0);
-    };
-    const int nk = p.K / 64;
-    stage(0, 0);
-    __syncthreads();
+    for (int j = 0; j < B_PER_WAVE; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + A_BYTES + (wave * B_PER_WAVE + j) * 1024), 16, 0, 0);
+  };
+  const int nk = p.K / 64;
+  int tile = t_beg + jb;
+  if (tile < t_end) { set_src(tile); stage(0, 0); }
+  for (; tile < t_end; tile += nbx) {
+    const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    __syncthreads();     // first k-stage landed; previous tile's staging (buffer 1) no longer read by anyone
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * 64);
       const char* as = smem + (kt & 1) * STAGE;
@@ -467,13 +480,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
       }
       __syncthreads();
     }
-    // epilogue: 64-row halves of the wave tile through this wave's 16 KiB staging slice (8 x 16 KiB <= 2 * STAGE)
+    // prefetch the next tile's first k-stage into buffer 0 under the epilogue; the epilogue stages 32-row slices of the
+    // wave tile through this wave's 8 KiB of buffer 1
+    if (tile + nbx < t_end) { set_src(tile + nbx); stage(0, 0); }
 #pragma unroll
-    for (int hh = 0; hh < MT / 2; ++hh) {
-      f32x16 (&sub)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * hh][0]);
-      nt_epilogue<T, TO, true>(p, sub, smem + wave * 16384, m0 + wm * WM + hh * 64, n0 + wn * 64, lane, false);
+    for (int i = 0; i < MT; ++i) {
+      f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
+      nt_epilogue<T, TO, true, 1>(p, sub, smem + STAGE + wave * 8192, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
     }
-    __syncthreads();
   }
 }
 
@@ -847,22 +861,13 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   const bool glds = dtype == FK_BF16 && (K % 64 == 0);
   if (glds && M >= 4096 && N % 256 == 0 && vec_epi) {         // large projections: 256 x 256 tiles, 1 block per CU (the 256x128
                                                                 // variant measured slower than 128x128 at N = 384)
-    const bool wide = (N % 256 == 0);
-    const int bn = wide ? 256 : 128;
-    const int64_t nt = fk_cdiv(M, 256) * (N / bn);
+    const int64_t nt = fk_cdiv(M, 256) * (N / 256);
     dim3 bgrid((unsigned)(nt < 256 ? nt : 256)), bblock(512);
-    const size_t bsh = 2 * (size_t)(256 + bn) * ROW_BYTES;
-    if (wide) {
-      if (out_dtype == FK_BF16) { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<bf16_t, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true); (void)once;
-        hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 256>), bgrid, bblock, bsh, s, p); }
-      else { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<float, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true); (void)once;
-        hipLaunchKernelGGL((gemm_nt_big_kernel<float, 256>), bgrid, bblock, bsh, s, p); }
-    } else {
-      if (out_dtype == FK_BF16) { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<bf16_t, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true); (void)once;
-        hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 128>), bgrid, bblock, bsh, s, p); }
-      else { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<float, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072), true); (void)once;
-        hipLaunchKernelGGL((gemm_nt_big_kernel<float, 128>), bgrid, bblock, bsh, s, p); }
-    }
+    const size_t bsh = 2 * (size_t)(256 + 256) * ROW_BYTES;
+    if (out_dtype == FK_BF16) { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<bf16_t, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess); (void)once;
+      hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 256>), bgrid, bblock, bsh, s, p); }
+    else { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<float, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess); (void)once;
+      hipLaunchKernelGGL((gemm_nt_big_kernel<float, 256>), bgrid, bblock, bsh, s, p); }
     FK_CHECK_LAUNCH(name);
     return FK_OK;
   }

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import weakref
+
 import torch
 
 from . import kernels as K
@@ -105,30 +107,64 @@ def wgrad(a: Tensor, b: Tensor, params: Sequence[Tensor], swiglu_interleaved: bo
 
 # --------------------------------------------------------------------------------------------- shadows
 class _Shadow:
-    __slots__ = ("stamp", "tensor")
+    """One compute-dtype weight copy.  `jobs` are the fk_cast_pack_rows calls that fill `tensor` from the masters
+    (src, dst view, transpose, rblk, rstride, roff); `params` are weak references (a shadow dies with its model)."""
+    __slots__ = ("stamp", "tensor", "jobs", "params", "dtype", "ptrs")
 
     def __init__(self):
-        self.stamp, self.tensor = None, None
+        self.stamp, self.tensor, self.jobs, self.params, self.dtype, self.ptrs = None, None, [], (), None, ()
+
+    def alive(self) -> bool:
+        """masters still exist and still live where the pack jobs read them (ParamArena moves parameter storage)"""
+        return all(r() is not None and r().data_ptr() == q for r, q in zip(self.params, self.ptrs))
+
+    def current_stamp(self):
+        return (_EPOCH, tuple(r()._version for r in self.params))
 
 
 _SHADOWS: dict = {}
+_REFRESH = {"sig": None, "table": None, "njobs": 0, "chunks": 0}
+
+
+def _run_jobs(ent: "_Shadow") -> None:
+    for src, dst, tr, rblk, rstride, roff in ent.jobs:
+        if rblk:
+            K.cast_pack_rows(src, dst, tr, rblk, rstride, roff)
+        else:
+            K.cast_pack(src, dst, transpose=tr)
+
+
+def _shadow_entry(key, params) -> "_Shadow":
+    ent = _SHADOWS.get(key)
+    if ent is not None and not ent.alive():       # the address was reused by another model's parameter
+        ent = None
+    if ent is None:
+        ent = _SHADOWS[key] = _Shadow()
+        ent.params = tuple(weakref.ref(p) for p in params)
+        ent.ptrs = tuple(p.data_ptr() for p in params)
+        ent.dtype = _COMPUTE_DTYPE
+    return ent
 
 
 def shadow(params: Sequence[Tensor], transpose: bool = False, pad_k: int = 0, pad_n: int = 0) -> Tensor:
     """Compute-dtype copy of cat(params, dim=0) ([sum N, K]); transposed -> [K, sum N]; pad_k / pad_n zero-pad
     the K / N extents (16-byte GEMM operand alignment).  1-D params (biases) are concatenated as vectors.
-    Rebuilt only when a master changed (tensor version counter) or the optimizer bumped the epoch."""
+    Re-packed only when a master changed (tensor version counter) or the optimizer bumped the epoch; the optimizer
+    re-packs every shadow of its parameters in one launch (refresh_shadows), so in a training loop this is a lookup."""
     dt = _COMPUTE_DTYPE
     key = (tuple((p.data_ptr(), tuple(p.shape)) for p in params), transpose, pad_k, pad_n, dt)
-    stamp = (_EPOCH, tuple(p._version for p in params))
-    ent = _SHADOWS.get(key)
-    if ent is None:
-        ent = _SHADOWS[key] = _Shadow()
+    ent = _shadow_entry(key, params)
+    stamp = ent.current_stamp()
     if ent.stamp == stamp:
+        return ent.tensor
+    if ent.tensor is not None and ent.jobs:        # same masters, new values: re-pack in place
+        _run_jobs(ent)
+        ent.stamp = stamp
         return ent.tensor
     p0 = params[0]
     for p in params:
         assert p.dtype == torch.float32, "master parameters must be float32 (compute dtype is set with set_compute_dtype)"
+    jobs = []
     if p0.dim() == 1:
         n = sum(p.numel() for p in params)
         if dt == torch.float32 and len(params) == 1:
@@ -137,7 +173,7 @@ def shadow(params: Sequence[Tensor], transpose: bool = False, pad_k: int = 0, pa
             out = torch.empty(n, dtype=dt, device=p0.device)
             off = 0
             for p in params:
-                K.cast_pack(p.detach().view(1, -1), out[off:off + p.numel()].view(1, -1))
+                jobs.append((p.detach().view(1, -1), out[off:off + p.numel()].view(1, -1), False, 0, 0, 0))
                 off += p.numel()
     else:
         Kd = p0.shape[1]
@@ -154,9 +190,11 @@ def shadow(params: Sequence[Tensor], transpose: bool = False, pad_k: int = 0, pa
                 src = p.detach()
                 assert src.dim() == 2 and src.shape[1] == Kd and src.is_contiguous()
                 dst = out[:Kd, off:off + src.shape[0]] if transpose else out[off:off + src.shape[0], :Kd]
-                K.cast_pack(src, dst, transpose=transpose)
+                jobs.append((src, dst, transpose, 0, 0, 0))
                 off += src.shape[0]
-    ent.stamp, ent.tensor = stamp, out
+    ent.jobs, ent.tensor = jobs, out
+    _run_jobs(ent)
+    ent.stamp = stamp
     return out
 
 
@@ -165,19 +203,48 @@ def shadow_swiglu(w1: Tensor, w3: Tensor, transpose: bool = False) -> Tensor:
     [K, 2H]) — the layout the fused GEMM epilogues (fk_gemm_nt_swiglu / fk_gemm_nt_dswiglu) expect."""
     dt = _COMPUTE_DTYPE
     key = (("swiglu", w1.data_ptr(), w3.data_ptr(), tuple(w1.shape)), transpose, dt)
-    stamp = (_EPOCH, w1._version, w3._version)
-    ent = _SHADOWS.get(key)
-    if ent is None:
-        ent = _SHADOWS[key] = _Shadow()
+    ent = _shadow_entry(key, (w1, w3))
+    stamp = ent.current_stamp()
     if ent.stamp == stamp:
         return ent.tensor
-    H, Kd = w1.shape
-    assert w3.shape == (H, Kd) and H % 8 == 0 and w1.dtype == torch.float32 and w1.is_contiguous() and w3.is_contiguous()
-    out = torch.empty((Kd, 2 * H) if transpose else (2 * H, Kd), dtype=dt, device=w1.device)
-    K.cast_pack_rows(w1.detach(), out, transpose, 4, 8, 0)
-    K.cast_pack_rows(w3.detach(), out, transpose, 4, 8, 4)
-    ent.stamp, ent.tensor = stamp, out
-    return out
+    if ent.tensor is None:
+        H, Kd = w1.shape
+        assert w3.shape == (H, Kd) and H % 8 == 0 and w1.dtype == torch.float32 and w1.is_contiguous() and w3.is_contiguous()
+        out = torch.empty((Kd, 2 * H) if transpose else (2 * H, Kd), dtype=dt, device=w1.device)
+        ent.jobs = [(w1.detach(), out, transpose, 4, 8, 0), (w3.detach(), out, transpose, 4, 8, 4)]
+        ent.tensor = out
+    _run_jobs(ent)
+    ent.stamp = stamp
+    return ent.tensor
+
+
+def refresh_shadows(params: Sequence[Tensor]) -> None:
+    """Re-pack, in ONE launch (fk_cast_pack_multi), every shadow built so far whose masters all belong to `params` — called by
+    the optimizer right after it updated the masters (one launch per step instead of one or two per weight)."""
+    ids = {id(p) for p in params}
+    for k in [k for k, e in _SHADOWS.items() if not e.alive()]:
+        del _SHADOWS[k]
+    ents = [e for e in _SHADOWS.values()
+            if e.jobs and e.dtype == _COMPUTE_DTYPE and e.tensor.is_cuda and all(id(r()) in ids for r in e.params)]
+    if not ents:
+        return
+    sig = tuple(id(e) for e in ents)
+    if _REFRESH["sig"] != sig:
+        import numpy as np
+        rec = np.dtype([("src", "<u8"), ("dst", "<u8"), ("lds", "<i8"), ("ldd", "<i8"), ("rows", "<i4"), ("cols", "<i4"),
+                        ("transpose", "<i4"), ("rblk", "<i4"), ("rstride", "<i4"), ("roff", "<i4"), ("chunk_begin", "<i8")])
+        assert rec.itemsize == 64
+        rows, chunks = [], 0
+        for e in ents:
+            for src, dst, tr, rblk, rstride, roff in e.jobs:
+                r, c = src.shape
+                rows.append((src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0), r, c, int(tr), rblk, rstride, roff, chunks))
+                chunks += (r * c + 1023) // 1024
+        tab = torch.from_numpy(np.array(rows, dtype=rec).view(np.uint8).copy()).to(ents[0].tensor.device)
+        _REFRESH.update(sig=sig, table=tab, njobs=len(rows), chunks=chunks, ents=ents)
+    K.cast_pack_multi(_REFRESH["table"], _REFRESH["njobs"], _REFRESH["chunks"], _COMPUTE_DTYPE)
+    for e in ents:
+        e.stamp = e.current_stamp()
 
 
 def _deinterleave_rows(t: Tensor, H: int):

@@ -344,6 +344,12 @@ def cast_pack_rows(src: Tensor, dst: Tensor, transpose: bool, rblk: int, rstride
     return dst
 
 
+def cast_pack_multi(jobs: Tensor, njobs: int, total_chunks: int, dtype: torch.dtype) -> None:
+    """jobs: device uint8 tensor holding njobs fk_pack_job records (see include/franken_hip.h)."""
+    assert jobs.dtype == torch.uint8 and jobs.is_cuda and jobs.numel() >= 64 * njobs
+    call("fk_cast_pack_multi", jobs.data_ptr(), njobs, total_chunks, fk_dtype(dtype), _stream())
+
+
 def cast(src: Tensor, dtype: torch.dtype) -> Tensor:
     assert src.is_contiguous()
     dst = torch.empty(src.shape, dtype=dtype, device=src.device)

@@ -239,6 +239,7 @@ class FusedAdamW:
         K.adamw_step_(self.arena.flat, self.arena.grad, self.m, self.v, self.t, g['lr'], g['betas'][0], g['betas'][1],
                       g['eps'], g['weight_decay'], clip=self.grad_clip or 0.0, grad_scale=scale, zero_grad=True)
         E.bump_weight_epoch()
+        E.refresh_shadows(self.arena.params)       # every weight shadow re-packed from the new masters in one launch
 
     def state_dict(self):
         return dict(t=self.t, m=self.m, v=self.v, param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])

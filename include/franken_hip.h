@@ -128,6 +128,15 @@ int fk_cast_pack(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t 
 /* same with a row map: source row j lands in destination row (j / rblk) * rstride + j % rblk + roff (rblk = 0: identity). */
 int fk_cast_pack_rows(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
                       int64_t rblk, int64_t rstride, int64_t roff, int dtype, void* stream);
+/* many fk_cast_pack_rows jobs in ONE launch: the per-step refresh of every weight shadow after the optimizer update
+ * (replaces ~150 tiny launches).  `jobs` is a DEVICE array; job j owns the 1024-element chunks
+ * [chunk_begin, next job's chunk_begin) of its rows*cols elements; total_chunks = end of the last job.                */
+typedef struct fk_pack_job {
+  const float* src; void* dst; int64_t lds, ldd;
+  int32_t rows, cols, transpose, rblk, rstride, roff;
+  int64_t chunk_begin;
+} fk_pack_job;
+int fk_cast_pack_multi(const fk_pack_job* jobs, int64_t njobs, int64_t total_chunks, int dtype, void* stream);
 int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* y = a + b (same dtype) */
 int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);

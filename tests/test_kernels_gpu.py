@@ -475,3 +475,31 @@ def test_attention_prefix_mask_from_token_ids(K, dtype):
     close(dq, qr.grad, dtype, atol32=5e-5, atol16=4e-2)
     close(dk, kr.grad, dtype, atol32=5e-5, atol16=4e-2)
     close(dv, vr.grad, dtype, atol32=5e-5, atol16=4e-2)
+
+
+def test_shadow_refresh_single_launch(K):
+    """fk_cast_pack_multi (engine.refresh_shadows): every weight shadow re-packed in one launch == the per-weight packs."""
+    import frankenstein_amd as fa
+    from frankenstein_amd import engine as E
+    fa.set_compute_dtype("bf16")
+    try:
+        g = torch.Generator().manual_seed(11)
+        ws = [torch.nn.Parameter(torch.randn(n, 40, generator=g).cuda()) for n in (24, 56, 8)]
+        w1, w3 = (torch.nn.Parameter(torch.randn(32, 40, generator=g).cuda()) for _ in range(2))
+        b = torch.nn.Parameter(torch.randn(77, generator=g).cuda())
+        sh = [E.shadow(ws), E.shadow(ws, transpose=True), E.shadow(ws[:1], pad_k=48), E.shadow_swiglu(w1, w3),
+              E.shadow_swiglu(w1, w3, transpose=True), E.shadow([b])]
+        with torch.no_grad():
+            for p in (*ws, w1, w3, b):
+                p.view(-1)[:] = torch.randn(p.numel(), generator=g).cuda()     # in-place through a view, like the optimizer
+        E.bump_weight_epoch()
+        E.refresh_shadows([*ws, w1, w3, b])
+        cat = torch.cat([w.detach() for w in ws]).bfloat16()
+        assert torch.equal(sh[0], cat) and torch.equal(sh[1], cat.t())
+        assert torch.equal(sh[2][:, :40], ws[0].detach().bfloat16()) and float(sh[2][:, 40:].abs().max()) == 0.0
+        inter = torch.stack([w1.detach().view(8, 4, 40), w3.detach().view(8, 4, 40)], 1).reshape(64, 40).bfloat16()
+        assert torch.equal(sh[3], inter) and torch.equal(sh[4], inter.t())
+        assert torch.equal(sh[5], b.detach().bfloat16())
+        assert E.shadow(ws) is sh[0] and E.shadow_swiglu(w1, w3) is sh[3]            # lookups, no re-pack
+    finally:
+        fa.set_compute_dtype("fp32")
