@@ -47,9 +47,10 @@ def bump_weight_epoch() -> None:
 
 # --------------------------------------------------------------------------------------------- weight-gradient stream
 # dW = dY^T X GEMMs do not feed the rest of the backward: with a flat gradient arena (train_utils.ParamArena) they are
-# accumulated straight into the arena on a SECOND HIP stream, so they run concurrently with the dX chain / attention
-# backward of the following layers (MFMA-light, memory-light kernels fill each other's stalls).  The optimizer joins the
-# stream before the update; DP buckets are all-reduced from that stream (GradSync).  Without an arena: plain returns.
+# accumulated straight into the arena (no temporary, no autograd add).  Optionally (FusedAdamW(overlap_wgrad=True) or
+# FK_WGRAD_STREAM=1) they run on a SECOND HIP stream beside the dX chain; the optimizer joins that stream before the update and
+# DP buckets are all-reduced from it (GradSync).  OFF by default: the large-tile GEMMs are one 128-KiB-LDS block per CU, and two
+# such grids from two streams split the CUs unevenly — measured 65 ms steps turning into 80-160 ms ones at random.
 _WGRAD_STREAM = None
 
 
@@ -103,6 +104,19 @@ def wgrad(a: Tensor, b: Tensor, params: Sequence[Tensor], swiglu_interleaved: bo
     # autograd still runs the parameters' post-accumulate-grad hooks (GradSync) after this Function returns, once per
     # backward and after the last use of a shared weight, so bucket readiness needs no extra signalling here
     return [None] * len(params)
+
+
+def norm_bwd(dh: Tensor, x2: Tensor, ln_w: Tensor, ln_b: Optional[Tensor], mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
+             kind: int = K.NORM_LAYER):
+    """K.norm_bwd whose dgamma / dbeta are accumulated straight into the gradient arena when the parameters live there
+    (returns Nones for them: no temporary, no autograd add); plain tensors otherwise."""
+    gw = _arena_grad(ln_w)
+    gb = _arena_grad(ln_b) if ln_b is not None else None
+    if gw is not None and (ln_b is None or gb is not None):
+        dx, _, _ = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dres, kind=kind, want_beta=ln_b is not None,
+                              dgamma=gw.view(-1), dbeta=None if gb is None else gb.view(-1), accumulate=True)
+        return dx, None, None
+    return K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dres, kind=kind, want_beta=ln_b is not None)
 
 
 # --------------------------------------------------------------------------------------------- shadows
@@ -323,6 +337,7 @@ class AttnBranch(torch.autograd.Function):
                       residual=x2 if residual else None)
         ctx.spec, ctx.has_ln, ctx.nw = spec, has_ln, len(qkv_w)
         ctx.flags = (ln_b is not None, pb is not None, qkv_b is not None)
+        ctx.ln_b = ln_b
         ctx.save_for_backward(x, ln_w, pw, *qkv_w, h if has_ln else None, mean, rstd, qkv, o, lse)
         return y.view(B, N, -1)
 
@@ -357,7 +372,7 @@ class AttnBranch(torch.autograd.Function):
         dws = wgrad(dqkv, h, list(qkv_w))
         dqb = K.colsum(dqkv) if has_qb else None
         if ctx.has_ln:
-            dx, dg, db = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, kind=nkind, want_beta=has_lnb)
+            dx, dg, db = norm_bwd(dh, x2, ln_w, ctx.ln_b, mean, rstd, dres=dy2 if residual else None, kind=nkind)
         else:
             dx, dg, db = (K.add(dh, dy2) if residual else dh), None, None
         return (dx.view(B, N, d), dg, db, dpw, dpb, dqb, None, *dws)
@@ -374,6 +389,7 @@ class CrossAttnBranch(torch.autograd.Function):
         HD = H * D
         x2, c2 = x.view(B * T, d), context.view(B * Nc, d)
         h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), ln_b.detach(), eps)
+        ctx.ln_b = ln_b
         q = K.gemm_nt(h, shadow([qw]))
         kv = K.gemm_nt(c2, shadow([kw, vw]))
         kv3 = kv.view(B, Nc, 2 * HD)
@@ -403,7 +419,7 @@ class CrossAttnBranch(torch.autograd.Function):
         (dqw,) = wgrad(dq, h, [qw])
         dctx = K.gemm_nt(dkv, shadow([kw, vw], transpose=True))
         dkw, dvw = wgrad(dkv, c2, [kw, vw])
-        dx, dg, db = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2)
+        dx, dg, db = norm_bwd(dh, x2, ln_w, ctx.ln_b, mean, rstd, dres=dy2)
         return dx.view(B, T, d), dctx.view(B, Nc, d), dg, db, dqw, dkw, dvw, dpw, None
 
 
@@ -433,6 +449,7 @@ class MlpBranch(torch.autograd.Function):
                       residual=x2 if residual else None)
         ctx.spec, ctx.has_ln, ctx.fused = spec, has_ln, fused
         ctx.flags = (ln_b is not None, up_b is not None, gate_w is not None, down_b is not None)
+        ctx.ln_b = ln_b
         ctx.save_for_backward(x, ln_w, up_w, gate_w, down_w, h if has_ln else None, mean, rstd, a, g)
         return y.view(*shp[:-1], y.shape[-1])
 
@@ -461,7 +478,7 @@ class MlpBranch(torch.autograd.Function):
             dups = wgrad(da, h, ups)
         dub = K.colsum(da) if has_ub else None
         if ctx.has_ln:
-            dx, dgam, dbet = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, dres=dy2 if residual else None, kind=nkind, want_beta=has_lnb)
+            dx, dgam, dbet = norm_bwd(dh, x2, ln_w, ctx.ln_b, mean, rstd, dres=dy2 if residual else None, kind=nkind)
         else:
             dx, dgam, dbet = (K.add(dh, dy2) if residual else dh), None, None
         return (dx.view(shp), dgam, dbet, dups[0], dub, dups[1] if gated else None, ddown, ddb, None)
@@ -482,6 +499,7 @@ class NormLinear(torch.autograd.Function):
         y = K.gemm_nt(h, shadow([w]), bias=None if b is None else shadow([b]),
                       out_dtype=torch.float32 if out_fp32 else None)
         ctx.has_ln, ctx.flags = has_ln, (ln_b is not None, b is not None)
+        ctx.ln_b = ln_b
         ctx.save_for_backward(x, ln_w, w, h if has_ln else None, mean, rstd)
         return y.view(*shp[:-1], y.shape[-1])
 
@@ -508,7 +526,7 @@ class NormLinear(torch.autograd.Function):
         dw = K.gemm_tn(dyp, h)[:nout]
         db = K.colsum(dy2) if has_b else None
         if ctx.has_ln:
-            dx, dg, dbe = K.norm_bwd(dh, x2, ln_w.detach(), mean, rstd, want_beta=has_lnb)
+            dx, dg, dbe = norm_bwd(dh, x2, ln_w, ctx.ln_b, mean, rstd)
         else:
             dx, dg, dbe = dh, None, None
         return dx.view(shp), dg, dbe, dw, db, None, None
@@ -518,14 +536,14 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, kind):
         y, mean, rstd = K.norm_fwd(x.contiguous(), w.detach(), None if b is None else b.detach(), eps, kind)
-        ctx.kind, ctx.has_b = kind, b is not None
+        ctx.kind, ctx.has_b, ctx.ln_b = kind, b is not None, b
         ctx.save_for_backward(x, w, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
-        dx, dg, db = K.norm_bwd(dy.contiguous(), x.contiguous(), w.detach(), mean, rstd, kind=ctx.kind, want_beta=ctx.has_b)
+        dx, dg, db = norm_bwd(dy.contiguous(), x.contiguous(), w, ctx.ln_b, mean, rstd, kind=ctx.kind)
         return dx, dg, db, None, None
 
 

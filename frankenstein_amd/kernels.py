@@ -255,21 +255,30 @@ def norm_fwd(x: Tensor, gamma: Tensor, beta: Optional[Tensor], eps: float, kind:
 
 
 def norm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
-             kind: int = NORM_LAYER, want_beta: bool = True):
-    """returns (dx, dgamma, dbeta) with dx = dres + norm_bwd(dy)."""
+             kind: int = NORM_LAYER, want_beta: bool = True, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
+             accumulate: bool = False):
+    """returns (dx, dgamma, dbeta) with dx = dres + norm_bwd(dy); given dgamma / dbeta buffers are written (+= when accumulate)."""
     x2, dy2 = _as2d(x), _as2d(dy)
     assert x2.is_contiguous() and dy2.is_contiguous() and dy2.dtype == x2.dtype
     rows, dim = x2.shape
     dx = torch.empty_like(x2)
-    dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(dim, dtype=torch.float32, device=x.device) if want_beta else None
+    if dgamma is None:
+        assert not accumulate
+        dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
+    if dbeta is None and want_beta:
+        assert not accumulate
+        dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
+    if not want_beta:
+        dbeta = None
+    for t in (dgamma, dbeta):
+        assert t is None or (t.dtype == torch.float32 and t.numel() == dim and t.is_contiguous())
     dres2 = None
     if dres is not None:
         dres2 = _as2d(dres)
         assert dres2.is_contiguous() and dres2.dtype == x2.dtype
     ws, nb = _ws(lib().fk_norm_bwd_workspace_bytes(rows, dim), x.device)
     call("fk_norm_bwd", dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres2),
-         dx.data_ptr(), dgamma.data_ptr(), _ptr(dbeta), rows, dim, kind, 0, fk_dtype(x), _ptr(ws), nb, _stream())
+         dx.data_ptr(), dgamma.data_ptr(), _ptr(dbeta), rows, dim, kind, int(accumulate), fk_dtype(x), _ptr(ws), nb, _stream())
     return dx.view(x.shape), dgamma, dbeta
 
 

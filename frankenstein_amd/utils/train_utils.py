@@ -213,9 +213,11 @@ class FusedAdamW:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999),
                  eps: float = 1e-8, grad_clip: Optional[float] = None, group=None, bucket_bytes: int = 8 << 20,
-                 overlap_wgrad: bool = True):
+                 overlap_wgrad: Optional[bool] = None):
         self.arena = ParamArena(model)
-        if overlap_wgrad and os.environ.get("FK_WGRAD_STREAM", "1") != "0" and self.arena.flat.is_cuda and E.wgrad_stream() is None:
+        if overlap_wgrad is None:
+            overlap_wgrad = os.environ.get("FK_WGRAD_STREAM", "0") == "1"     # see engine.py: off by default
+        if overlap_wgrad and self.arena.flat.is_cuda and E.wgrad_stream() is None:
             E.enable_wgrad_stream(True)
         self.m = torch.zeros_like(self.arena.flat)
         self.v = torch.zeros_like(self.arena.flat)

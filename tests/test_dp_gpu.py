@@ -41,7 +41,7 @@ def _batch(B):
     return torch.from_numpy(synth.make_inputs(B, 32, 16)).cuda(), torch.from_numpy(synth.make_motion_targets(B, 8, 12)).cuda()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
@@ -49,7 +49,8 @@ def _worker(rank, world, port, out):
     from frankenstein_amd.utils import train_utils as tu
     m = _build()
     cfg = tu.TrainConfig(mixed_precision=False, use_scheduler=False, learning_rate=1e-3)
-    opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=cfg.weight_decay, grad_clip=cfg.grad_clip, bucket_bytes=64 << 10)
+    opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=cfg.weight_decay, grad_clip=cfg.grad_clip, bucket_bytes=64 << 10,
+                        overlap_wgrad=overlap)
     assert opt.sync.world == world and len(opt.sync.buckets) > 1
     x, y = _batch(4)
     for step in range(2):
@@ -60,11 +61,12 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank_full_batch():
+@pytest.mark.parametrize("overlap", [False, True], ids=["one-stream", "wgrad-side-stream"])
+def test_two_ranks_equal_one_rank_full_batch(overlap):
     import torch.multiprocessing as mp
     world = 2
     out = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, overlap), nprocs=world, join=True)
     assert len(out) == world
     np.testing.assert_array_equal(out[0], out[1])            # replicas stay bit-identical
     # single process, full batch (L1 loss is a mean over equal-sized shards -> mean of shard gradients == full gradient)
