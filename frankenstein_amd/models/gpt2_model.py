@@ -88,6 +88,32 @@ class Block(nn.Module):
         x = self.attn.branch(_prep(x), self.ln_1, True)
         return self.mlp.branch(x, self.ln_2, True)
 
+    @torch.no_grad()
+    def forward_cached(self, x, kv, pos):
+        """Incremental inference step: x [B, t, d] are the tokens at positions pos..pos+t-1, kv [B, Tmax, 2d] this layer's
+        key|value cache (rows < pos filled by earlier calls).  Same kernels as the training forward; attention is the
+        causal mask with the query offset pos, so a t = 1 step costs O(pos) instead of re-running the whole sequence
+        (the reference re-forwards everything per token, models/gpt2_model.py:336-340)."""
+        B, t, d = x.shape
+        at, ml = self.attn, self.mlp
+        H, D = at.n_head, d // at.n_head
+        x2 = x.reshape(B * t, d)
+        h, _, _ = K.norm_fwd(x2, self.ln_1.weight.detach(), None if self.ln_1.bias is None else self.ln_1.bias.detach(), self.ln_1.eps)
+        qkv = K.gemm_nt(h, E.shadow([at.c_attn.weight]), None if at.c_attn.bias is None else E.shadow([at.c_attn.bias]))
+        q3 = qkv.view(B, t, 3 * d)
+        for b in range(B):                                   # append k|v rows of the new tokens
+            K.copy2d(q3[b, :, d:], kv[b, pos:pos + t])
+        k = kv[:, :pos + t, :d].unflatten(-1, (H, D))
+        v = kv[:, :pos + t, d:].unflatten(-1, (H, D))
+        o, _ = K.attn_fwd(q3[..., :d].unflatten(-1, (H, D)), k, v, Mask(MASK_CAUSAL, q_off=pos))
+        x2 = K.gemm_nt(o.view(B * t, d), E.shadow([at.c_proj.weight]), None if at.c_proj.bias is None else E.shadow([at.c_proj.bias]),
+                       residual=x2)
+        h, _, _ = K.norm_fwd(x2, self.ln_2.weight.detach(), None if self.ln_2.bias is None else self.ln_2.bias.detach(), self.ln_2.eps)
+        a = K.gemm_nt(h, E.shadow([ml.c_fc.weight]), None if ml.c_fc.bias is None else E.shadow([ml.c_fc.bias]))
+        x2 = K.gemm_nt(K.gelu_fwd(a), E.shadow([ml.c_proj.weight]), None if ml.c_proj.bias is None else E.shadow([ml.c_proj.bias]),
+                       residual=x2)
+        return x2.view(B, t, d)
+
 
 @dataclass
 class GPTConfig:
@@ -240,14 +266,47 @@ class GPT(nn.Module):
         return flops_per_iter / dt / peak_flops
 
     @torch.no_grad()
-    def generate(self, idx, max_new_tokens, prefix=None, temperature=1.0, top_k=None):
-        """Sampling loop around the kernel forward (full re-forward per token like the reference; host-side glue)."""
-        for _ in range(max_new_tokens):
-            _, logits = self(idx, prefix=prefix)
-            logits = logits[:, -1, :].float() / temperature
+    def _cached_logits(self, idx_new, cache, pos, prefix=None):
+        """last-position logits [B, V] after feeding prefix (first call only) + idx_new [B, t] at positions pos..; updates cache."""
+        wte, wpe = self.transformer.wte.weight, self.transformer.wpe.weight
+        x = K.gpt_embed_fwd(idx_new.contiguous(), prefix, wte.detach(), wpe.detach()[pos:], E.compute_dtype())
+        t = x.shape[1]
+        for li, block in enumerate(self.transformer.h):
+            x = block.forward_cached(x, cache[li], pos)
+        ln = self.transformer.ln_f
+        last = x[:, -1, :].contiguous()
+        h, _, _ = K.norm_fwd(last, ln.weight.detach(), None if ln.bias is None else ln.bias.detach(), ln.eps)
+        V = self.config.vocab_size
+        npad = (V + 7) // 8 * 8                               # 16-byte rows for the vector GEMM epilogue
+        logits = K.gemm_nt(h, E.shadow([self.lm_head.weight], pad_n=npad), out_dtype=torch.float32)[:, :V]
+        return logits, pos + t
+
+    @torch.no_grad()
+    def generate(self, idx, max_new_tokens, prefix=None, temperature=1.0, top_k=None, use_cache=True):
+        """Sampling loop of the reference (models/gpt2_model.py:328-353: temperature, top-k crop, softmax, multinomial; returns
+        the first sample's ids).  With use_cache (default) the prefix + prompt are run once and every new token is one
+        incremental step against per-layer key/value caches; when the sequence would outgrow block_size the reference's
+        crop-and-re-forward path is used instead."""
+        B, t0 = idx.shape
+        t_ctx = 0 if prefix is None else prefix.shape[1]
+        total = t_ctx + t0 + max_new_tokens
+        cached = use_cache and total <= self.config.block_size and max_new_tokens > 0
+        if cached:
+            d = self.config.n_embd
+            cache = [torch.empty((B, total, 2 * d), dtype=E.compute_dtype(), device=idx.device) for _ in self.transformer.h]
+            logits, pos = self._cached_logits(idx, cache, 0, None if prefix is None else _prep(prefix))
+        for it in range(max_new_tokens):
+            if cached:
+                if it > 0:
+                    logits, pos = self._cached_logits(idx[:, -1:], cache, pos)
+                logits = logits.float() / temperature
+            else:
+                idx_cond = idx if idx.size(1) <= self.config.block_size else idx[:, -self.config.block_size:]
+                _, lg = self(idx_cond, prefix=prefix)
+                logits = lg[:, -1, :].float() / temperature
             if top_k is not None:
                 v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
                 logits[logits < v[:, [-1]]] = -float('Inf')
             probs = torch.softmax(logits, dim=-1)
             idx = torch.cat((idx, torch.multinomial(probs, num_samples=1)), dim=1)
-        return idx
+        return idx[0]

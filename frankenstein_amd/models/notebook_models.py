@@ -71,4 +71,4 @@ class Franky(nn.Module):
         xin = torch.from_numpy(x[None]).to(self.device).float()
         prefix = self.brain_model(xin)
         ids = torch.full((1, 1), eot, dtype=torch.long, device=self.device)
-        return self.llm_model.generate(ids, max_new_tokens, prefix=prefix, temperature=temperature, top_k=top_k)[0]
+        return self.llm_model.generate(ids, max_new_tokens, prefix=prefix, temperature=temperature, top_k=top_k)

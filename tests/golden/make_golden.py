@@ -107,6 +107,9 @@ def params_of(model):
 
 
 def save(name, **arrs):
+    only = os.environ.get("FK_GOLDEN_ONLY")          # regenerate a single fixture without touching the others
+    if only and name not in only.split(","):
+        return
     np.savez_compressed(OUT / f"{name}.npz", **arrs)
     sz = (OUT / f"{name}.npz").stat().st_size
     print(f"wrote {name}.npz  {sz/1024:.1f} KiB")
@@ -217,6 +220,17 @@ def main():
              last_logits=last.detach().numpy(), targets=tk.numpy(), prefix_grad=prefix.grad.numpy(),
              loss_noprefix=np.array(float(loss_np)), logits_noprefix=logits_np.detach().numpy(),
              **{"grad/" + k: v.numpy() for k, v in grads_of(g).items()})
+        if bias:
+            # greedy decoding (top_k=1 makes GPT.generate deterministic): tokens + the last-position logits it samples from
+            g.eval()
+            start = idx[:1, :4].clone()
+            gen = g.generate(start.clone(), max_new_tokens=8, prefix=prefix[:1].detach(), top_k=1)
+            steps, cur = [], start.clone()
+            for _ in range(8):
+                _, lg = g(cur, prefix=prefix[:1].detach())
+                steps.append(lg[0, -1].detach().numpy())
+                cur = torch.cat([cur, lg[:, -1].argmax(-1, keepdim=True)], 1)
+            save("gpt_generate", start=start.numpy(), tokens=gen.numpy(), step_logits=np.stack(steps), tokens_argmax=cur[0].numpy())
 
     # ---- cfg1: Franky(BrainEncoder + gpt2-nano), B=4, T=200, + 2 optimizer steps
     enc = bf.MAEConfig(window_size=200, n_electrodes=256, patch_size=25, dim=128, n_layers=2, head_dim=32,

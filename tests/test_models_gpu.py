@@ -123,6 +123,35 @@ def test_gpt_small_fp32(golden, bias):
     np.testing.assert_allclose(logits2.float().cpu().detach().numpy(), z["logits_noprefix"], atol=1e-4)
 
 
+@pytest.mark.parametrize("use_cache", [True, False], ids=["kv-cache", "re-forward"])
+def test_gpt_generate_greedy_matches_reference(golden, use_cache):
+    """SURVEY 8f rank 2: GPT.generate (models/gpt2_model.py:328-353).  top_k=1 makes the reference's sampling loop deterministic;
+    the key/value-cached incremental path and the reference-style full re-forward must both reproduce its tokens, and the
+    cached path's per-step last-position logits must match the reference's within the fp32 parity tolerance."""
+    z = golden("gpt_generate")
+    cfgo, prefix, tk, idx = C.gpt_small(True)
+    g = load_synth(mk_gpt(cfgo)).eval()
+    start = torch.from_numpy(z["start"]).cuda()
+    assert torch.equal(start.cpu(), idx[:1, :4])
+    pf = prefix[:1].cuda()
+    out = g.generate(start.clone(), max_new_tokens=8, prefix=pf, top_k=1, use_cache=use_cache)
+    assert out.dim() == 1 and out.cpu().tolist() == z["tokens"].tolist()
+    if use_cache:
+        from frankenstein_amd import engine as E
+        d, total = cfgo.n_embd, 5 + 4 + 8
+        cache = [torch.empty((1, total, 2 * d), dtype=E.compute_dtype(), device="cuda") for _ in g.transformer.h]
+        from frankenstein_amd.models.brainformer import _prep
+        logits, pos = g._cached_logits(start, cache, 0, _prep(pf))
+        toks = torch.from_numpy(z["tokens"]).cuda()
+        for i in range(8):
+            np.testing.assert_allclose(logits.float().cpu().numpy()[0], z["step_logits"][i], atol=1e-4)
+            if i < 7:
+                logits, pos = g._cached_logits(toks[None, 4 + i:5 + i], cache, pos)
+        # batched decode (B = 3, ragged nothing: same prompt length) agrees with the per-sample runs
+        outs = [g.generate(idx[b:b + 1, :4].cuda(), 5, prefix=prefix[b:b + 1].cuda(), top_k=1) for b in range(3)]
+        assert g.generate(idx[:, :4].cuda(), 5, prefix=prefix.cuda(), top_k=1).cpu().tolist() == outs[0].cpu().tolist()
+
+
 def build_franky():
     from frankenstein_amd.models.notebook_models import BrainEncoder, Franky
     bcfg, gcfg, x, tok = C.cfg1()
