@@ -141,6 +141,18 @@ int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
 /* y = a + b (same dtype) */
 int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
 
+/* ---- input pipeline on device (utils/data_utils.py:115-155 process_signal, :243-267 pad_truncate_brain_list).
+ * Trials are packed row-wise: trial i = rows off[i] .. off[i+1]-1 of x [total_rows, C] fp32; block[i] in [0, nblocks) is its
+ * recording block.  fk_block_stats: mean / population std per (block, channel) over every row of the block's trials
+ * (fp64 accumulation, deterministic; std == 0 -> 1 like :145).  fk_zscore_smooth_pad: out[i, t, :] =
+ * gaussian_filter1d((x_i - mean) / std, sigma, axis 0, mode 'reflect', radius 4)[t] for t < min(len_i, Tmax), zeros after
+ * (the filter sees the whole trial, truncation to Tmax comes last, as in the reference).                          */
+size_t fk_block_stats_workspace_bytes(int64_t ntrials, int64_t C);
+int fk_block_stats(const float* x, const int64_t* off, const int32_t* block, int64_t ntrials, int64_t C, int64_t nblocks,
+                   float* mean, float* stdv, void* workspace, size_t workspace_bytes, void* stream);
+int fk_zscore_smooth_pad(const float* x, const int64_t* off, const int32_t* block, const float* mean, const float* stdv,
+                         float* out, int64_t ntrials, int64_t C, int64_t Tmax, double sigma, void* stream);
+
 /* ---- MAE gather / scatter (models/brainformer.py:429-457,468,472): rows of W elements.
  * gather : dst[b, i, :] = src[b, idx[b,i] (% idx_mod), :]     (src_bs = 0 broadcasts one table: embedding / pos-emb lookup)
  * scatter: dst[b, idx[b,i], :] = src[b, i, :]                 dtypes converted on the fly; batch strides in elements.

@@ -314,5 +314,27 @@ def main():
          **{"grad/" + k: v.numpy() for k, v in grads_of(m).items()})
 
 
+def pipeline_golden():
+    """utils/data_utils.py process_signal + pad_truncate_brain_list on ragged synthetic trials (float64 like the .mat arrays)."""
+    sys.modules.setdefault("scipy.io", __import__("scipy.io"))
+    du = importlib.machinery.SourceFileLoader("ref_data_utils", str(REF / "utils" / "data_utils.py")).load_module()
+    rng = np.random.default_rng(7)
+    lens = [37, 52, 3, 64, 45, 9]
+    blocks = np.array([5, 5, 9, 9, 5, 2])
+    volt = [rng.normal(0.5 * (i % 3), 1.0 + 0.2 * i, size=(n, 8)).astype(np.float32) for i, n in enumerate(lens)]
+    spk = [rng.poisson(2.0, size=(n, 8)).astype(np.float32) for n in lens]
+    for v in volt:
+        v[:, 3] = 1.25                                  # a dead channel: std == 0 -> 1
+    proc = du.process_signal([v.astype(np.float64) for v in volt], [s.astype(np.float64) for s in spk], blocks)
+    padded = np.stack(du.pad_truncate_brain_list(list(proc), 48)).astype(np.float32)
+    zs = du.z_score_per_block_scaling([np.concatenate([v, s], 1).astype(np.float64) for v, s in zip(volt, spk)], list(blocks))
+    save("pipeline", lens=np.array(lens), blocks=blocks, padded=padded, **{f"volt{i}": v for i, v in enumerate(volt)},
+         **{f"spk{i}": s for i, s in enumerate(spk)}, **{f"z{i}": z.astype(np.float32) for i, z in enumerate(zs)})
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("FK_GOLDEN_ONLY") == "pipeline":
+        pipeline_golden()
+    else:
+        main()
+        pipeline_golden()

@@ -347,3 +347,23 @@ def test_simple_mae_small_fp32(golden):
     check_full_grads(m, z)
     l2, _ = m(x)                                    # random index sets drawn on the device
     assert torch.isfinite(l2)
+
+
+def test_input_pipeline_matches_reference(golden):
+    """block-wise z-score (std == 0 -> 1) + Gaussian smoothing + pad / truncate on device vs
+    utils/data_utils.py process_signal / pad_truncate_brain_list / z_score_per_block_scaling run on the reference (float64)."""
+    from frankenstein_amd.utils import data_utils as du
+    z = golden("pipeline")
+    n = len(z["lens"])
+    volt, spk = [z[f"volt{i}"] for i in range(n)], [z[f"spk{i}"] for i in range(n)]
+    brain = [np.concatenate([v, s], axis=1) for v, s in zip(volt, spk)]
+    out = du.process_and_pad(brain, z["blocks"], max_length=48)
+    assert out.shape == (n, 48, 16) and out.dtype == torch.float32
+    np.testing.assert_allclose(out.cpu().numpy(), z["padded"], atol=2e-5)       # incl. the 64-row trial truncated AFTER smoothing
+    assert float(out[2, 3:].abs().max()) == 0.0                                    # 3-row trial: zero padding
+    proc = du.process_signal(volt, spk, z["blocks"])
+    for i in range(n):
+        np.testing.assert_allclose(proc[i][:48], z["padded"][i, :min(48, z["lens"][i])], atol=2e-5)
+    zs = du.z_score_per_block_scaling(brain, list(z["blocks"]))
+    for i in range(n):
+        np.testing.assert_allclose(zs[i], z[f"z{i}"], atol=2e-5)
