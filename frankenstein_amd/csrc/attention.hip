@@ -564,8 +564,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
         mma32<T>(dp, vf, gf[s]);
       }
       if (!boundary) {
+        // packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): ~1 % on the backward; the same change made the forward slower
+        const f32x2 c2 = {c, c}, nl2 = {-lse2, -lse2}, ndl2 = {-dl, -dl};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r] * c - lse2) * (dp[r] - dl);
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 x = {sc[r], sc[r + 1]}, d = {dp[r], dp[r + 1]};
+          x = __builtin_elementwise_fma(x, c2, nl2);
+          x[0] = __builtin_amdgcn_exp2f(x[0]);
+          x[1] = __builtin_amdgcn_exp2f(x[1]);
+          x *= d + ndl2;
+          sc[r] = x[0];
+          sc[r + 1] = x[1];
+        }
       } else {
         const int qpos = qrow + p.q_off;
 #pragma unroll
@@ -736,12 +746,20 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
         for (int g = 0; g < 4; ++g) {
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + 32 * u + 8 * g + 4 * lh);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(std_ + 32 * u + 8 * g + 4 * lh);
+          const f32x2 c2 = {c, c};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 4; j += 2) {
             const int r = 4 * g + j;
-            const float pv = __builtin_amdgcn_exp2f(sc[u][r] * c - l4[j]);
-            sc[u][r] = pv;                          // P
-            dp[u][r] = pv * (dp[u][r] - d4[j]);     // dS (scale folded into the final store)
+            f32x2 x = {sc[u][r], sc[u][r + 1]}, d = {dp[u][r], dp[u][r + 1]};
+            const f32x2 nl = {-l4[j], -l4[j + 1]}, nd = {-d4[j], -d4[j + 1]};
+            x = __builtin_elementwise_fma(x, c2, nl);
+            x[0] = __builtin_amdgcn_exp2f(x[0]);
+            x[1] = __builtin_amdgcn_exp2f(x[1]);
+            d = x * (d + nd);
+            sc[u][r] = x[0];                        // P
+            sc[u][r + 1] = x[1];
+            dp[u][r] = d[0];                        // dS (scale folded into the final store)
+            dp[u][r + 1] = d[1];
           }
         }
       } else {
