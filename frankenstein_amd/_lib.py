@@ -52,6 +52,11 @@ SIGNATURES = {
     "fk_prefix_mask": (_int, [_p, _p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "fk_copy2d": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _p]),
     "fk_add2d": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
+    "fk_im2col1d": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
+    "fk_col2im1d": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
+    "fk_elu_fwd": (_int, [_p, _p, _i64, _int, _p]),
+    "fk_elu_bwd": (_int, [_p, _p, _p, _i64, _int, _p]),
+    "fk_argmax_rows": (_int, [_p, _i64, _p, _i64, _i64, _int, _p]),
     "fk_block_stats_workspace_bytes": (_sz, [_i64, _i64]),
     "fk_block_stats": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
     "fk_zscore_smooth_pad": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f64, _p]),

@@ -647,6 +647,111 @@ def mse_loss(pred: Tensor, target: Tensor, row_weight: Optional[Tensor] = None) 
     return L1Loss.apply(pred, target, True, row_weight)
 
 
+# --------------------------------------------------------------------------------------------- conv stack
+def _conv_shadow(w: Tensor, mode: str, transpose: bool) -> Tensor:
+    """GEMM-shaped compute-dtype view of a convolution weight (re-packed lazily when the master changes):
+    mode "conv":  nn.Conv1d weight [Cout, Cin, K]          -> W' [Cout, K*Cin],   W'[o, k*Cin + c] = W[o, c, k]
+    mode "convT": nn.ConvTranspose1d weight [Cin, Cout, 2s] -> W' [s*Cout, 2*Cin], row (r, o), taps (x[j-1], x[j]):
+                  W'[(r,o), c] = W[c, o, r + s],  W'[(r,o), Cin + c] = W[c, o, r]      (models/vq_brain.py:31-45)."""
+    key = (("conv", mode, w.data_ptr(), tuple(w.shape)), transpose, _COMPUTE_DTYPE)
+    ent = _shadow_entry(key, (w,))
+    stamp = ent.current_stamp()
+    if ent.stamp == stamp:
+        return ent.tensor
+    wd = w.detach()
+    if mode == "conv":
+        g = wd.permute(0, 2, 1).reshape(wd.shape[0], -1)
+    else:
+        cin, cout, k2 = wd.shape
+        s_ = k2 // 2
+        g = torch.cat([wd[:, :, s_:].permute(2, 1, 0), wd[:, :, :s_].permute(2, 1, 0)], dim=2).reshape(s_ * cout, 2 * cin)
+    g = (g.t() if transpose else g).contiguous()
+    ent.tensor = g if _COMPUTE_DTYPE == torch.float32 else K.cast(g, _COMPUTE_DTYPE)
+    ent.stamp = stamp
+    return ent.tensor
+
+
+def _conv_wgrad_to_master(dwp: Tensor, w: Tensor, mode: str) -> Tensor:
+    """inverse of the _conv_shadow layout for the fp32 weight gradient"""
+    if mode == "conv":
+        cout, cin, k = w.shape
+        return dwp.view(cout, k, cin).permute(0, 2, 1).contiguous()
+    cin, cout, k2 = w.shape
+    s_ = k2 // 2
+    t = dwp.view(s_, cout, 2, cin)                       # [r, o, tap, c]
+    return torch.cat([t[:, :, 1].permute(2, 1, 0), t[:, :, 0].permute(2, 1, 0)], dim=2).contiguous()   # [c, o, (r | r + s)]
+
+
+class CausalConv1dFn(torch.autograd.Function):
+    """Channels-last causal convolution as im2col + MFMA GEMM (bias and an optional residual fused in the GEMM epilogue).
+    mode "conv": y[b, t, :] = sum_k W[:, :, k] x[b, t*stride + k*dil - dil*(K-1), :] + bias  (CausalConv1d, models/vq_brain.py:22-28)
+    mode "convT": CausalConvTranspose1d(kernel 2s, stride s): [B, T, Cin] -> [B, s*T, Cout]  (:31-45)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, dil, mode, residual):
+        B, T, cin = x.shape
+        if mode == "conv":
+            cout, _, ks = w.shape
+            st, n_rep = stride, 1
+        else:
+            _, cout, k2 = w.shape
+            ks, st, n_rep = 2, 1, k2 // 2
+            assert k2 == 2 * stride and dil == 1, "CausalConvTranspose1d is built for kernel_size = 2 * stride"
+        x = x.contiguous()
+        cols = x.view(B * T, cin) if (ks == 1 and st == 1) else K.im2col1d(x, ks, st, dil)
+        bias = None
+        if b is not None:
+            bias = shadow([b]) if n_rep == 1 else K.cast(b.detach().repeat(n_rep), _COMPUTE_DTYPE)
+        res2 = None if residual is None else residual.contiguous().view(cols.shape[0], -1)
+        y = K.gemm_nt(cols, _conv_shadow(w, mode, False), bias, residual=res2)
+        tout = (T - 1) // st + 1
+        ctx.cfg = (B, T, cin, ks, st, dil, mode, n_rep, b is not None, residual is not None)
+        ctx.save_for_backward(x, w)
+        return y.view(B, tout * n_rep, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, T, cin, ks, st, dil, mode, n_rep, has_b, has_res = ctx.cfg
+        dy = dy.contiguous()
+        dy2 = dy.view(-1, dy.shape[-1] * n_rep)
+        cols = x.view(B * T, cin) if (ks == 1 and st == 1) else K.im2col1d(x, ks, st, dil)
+        dcols = K.gemm_nt(dy2, _conv_shadow(w, mode, True))
+        dx = dcols.view(B, T, cin) if (ks == 1 and st == 1) else K.col2im1d(dcols, B, T, cin, ks, st, dil)
+        dw = _conv_wgrad_to_master(K.gemm_tn(dy2, cols), w, mode)
+        db = None
+        if has_b:
+            db = K.colsum(dy2)
+            if n_rep > 1:
+                db = db.view(n_rep, -1).sum(0)
+        return dx, dw, db, None, None, None, (dy if has_res else None)
+
+
+class EluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return K.elu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.elu_bwd(x, dy.contiguous())
+
+
+class StraightThrough(torch.autograd.Function):
+    """forward: the quantized vectors; backward: the gradient goes to the encoder output unchanged (x + (q - x).detach())."""
+
+    @staticmethod
+    def forward(ctx, x, q):
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        return dq, None
+
+
 # --------------------------------------------------------------------------------------------- MAE pieces (SURVEY §8f)
 class GatherRows(torch.autograd.Function):
     """out[b, i, :] = src[b, idx[b, i], :]  (models/brainformer.py:441,468); idx rows are unique per sample."""

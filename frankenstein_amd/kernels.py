@@ -423,6 +423,46 @@ def add2d_(dst: Tensor, src: Tensor) -> Tensor:
     return dst
 
 
+# ------------------------------------------------------------------------------------------- conv (VQ-VAE tokenizer)
+def im2col1d(x: Tensor, ksize: int, stride: int = 1, dil: int = 1) -> Tensor:
+    """x [B, T, C] -> cols [B * Tout, ksize * C] with the causal left padding dil * (ksize - 1); Tout = (T - 1) // stride + 1."""
+    assert x.dim() == 3 and x.is_contiguous()
+    B, T, C = x.shape
+    tout = (T - 1) // stride + 1
+    cols = torch.empty((B * tout, ksize * C), dtype=x.dtype, device=x.device)
+    call("fk_im2col1d", x.data_ptr(), cols.data_ptr(), B, T, C, ksize, stride, dil, fk_dtype(x), _stream())
+    return cols
+
+
+def col2im1d(dcols: Tensor, B: int, T: int, C: int, ksize: int, stride: int = 1, dil: int = 1) -> Tensor:
+    tout = (T - 1) // stride + 1
+    assert dcols.is_contiguous() and dcols.shape == (B * tout, ksize * C)
+    dx = torch.empty((B, T, C), dtype=dcols.dtype, device=dcols.device)
+    call("fk_col2im1d", dcols.data_ptr(), dx.data_ptr(), B, T, C, ksize, stride, dil, fk_dtype(dcols), _stream())
+    return dx
+
+
+def elu_fwd(x: Tensor) -> Tensor:
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    call("fk_elu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), fk_dtype(x), _stream())
+    return y
+
+
+def elu_bwd(x: Tensor, dy: Tensor) -> Tensor:
+    assert x.is_contiguous() and dy.is_contiguous() and dy.dtype == x.dtype and dy.shape == x.shape
+    dx = torch.empty_like(x)
+    call("fk_elu_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), fk_dtype(x), _stream())
+    return dx
+
+
+def argmax_rows(x: Tensor) -> Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1
+    idx = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    call("fk_argmax_rows", x.data_ptr(), x.stride(0), idx.data_ptr(), x.shape[0], x.shape[1], fk_dtype(x), _stream())
+    return idx
+
+
 # ------------------------------------------------------------------------------------------- losses
 def l1_loss_fwd(pred: Tensor, target: Tensor, squared: bool = False, row_weight: Optional[Tensor] = None) -> Tensor:
     """-> loss2 fp32[2] = {mean (weighted) |d| or d^2, weight sum}; row_weight: fp32 [rows] with rows = numel / last dim."""

@@ -52,6 +52,7 @@ def make_tensor(name: str, shape: Sequence[int], seed: int = SEED_WEIGHTS) -> np
     * biases / 1-D                                  : 0.1 N(0,1)
     * 2-D Linear / Embedding                        : N(0, 1/sqrt(fan_in))
     * 3-D (space_embedding, learnable_queries)      : 0.5 N(0,1)
+    * 3-D convolution ``weight`` [.., .., K]         : N(0, 1/sqrt(shape[1]*shape[2]))
     Activations stay O(1) so softmax / norms are exercised non-trivially.
     """
     rng = np.random.default_rng(_key_seed(seed, name))
@@ -64,6 +65,8 @@ def make_tensor(name: str, shape: Sequence[int], seed: int = SEED_WEIGHTS) -> np
         return (0.1 * z).astype(np.float32)
     if len(shape) == 2:
         return (z / np.sqrt(np.float32(shape[1]))).astype(np.float32)
+    if len(shape) == 3 and leaf == "weight":
+        return (z / np.sqrt(np.float32(shape[1] * shape[2]))).astype(np.float32)
     return (0.5 * z).astype(np.float32)
 
 

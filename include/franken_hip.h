@@ -141,6 +141,18 @@ int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
 /* y = a + b (same dtype) */
 int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
 
+/* ---- VQ-VAE tokenizer convolutions (models/vq_brain.py), channels-last [B, T, C], causal left padding dil*(K-1):
+ * fk_im2col1d: cols[b, t, k, :] = x[b, t*stride + k*dil - pad, :] (zeros outside), Tout = (T-1)/stride + 1, so that
+ *   CausalConv1d (:22-28) = fk_gemm_nt(cols, W') with W'[o, k*Cin + c] = W[o, c, k], and CausalConvTranspose1d(kernel 2s,
+ *   stride s, :31-45) = the same with K = 2 taps and s*Cout phase-major output columns viewed as [B, s*T, Cout].
+ * fk_col2im1d: adjoint of fk_im2col1d (dx from dcols; gather form, deterministic).   fk_elu_*: nn.ELU().
+ * fk_argmax_rows: idx[r] = argmax_c x[r, c] (first on ties): nearest code of the cosine-similarity VQ lookup.          */
+int fk_im2col1d(const void* x, void* cols, int64_t B, int64_t T, int64_t Cin, int64_t K, int64_t stride, int64_t dil, int dtype, void* stream);
+int fk_col2im1d(const void* dcols, void* dx, int64_t B, int64_t T, int64_t Cin, int64_t K, int64_t stride, int64_t dil, int dtype, void* stream);
+int fk_elu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int fk_elu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+int fk_argmax_rows(const void* x, int64_t ld, int64_t* idx, int64_t rows, int64_t cols, int dtype, void* stream);
+
 /* ---- input pipeline on device (utils/data_utils.py:115-155 process_signal, :243-267 pad_truncate_brain_list).
  * Trials are packed row-wise: trial i = rows off[i] .. off[i+1]-1 of x [total_rows, C] fp32; block[i] in [0, nblocks) is its
  * recording block.  fk_block_stats: mean / population std per (block, channel) over every row of the block's trials

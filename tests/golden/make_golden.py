@@ -332,9 +332,40 @@ def pipeline_golden():
          **{f"spk{i}": s for i, s in enumerate(spk)}, **{f"z{i}": z.astype(np.float32) for i, z in enumerate(zs)})
 
 
+def vq_golden():
+    """models/vq_brain.py convolution stack (Encoder, Decoder, custom_l1_loss, calculate_perp) on CPU; the third-party VQ layer
+    (absent, unpinned) is stubbed out and bypassed: decoder(encoder(x))."""
+    for name, attrs in (("vector_quantize_pytorch", ("ResidualVQ", "VectorQuantize")), ("pytorch_model_summary", ("summary",))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            for a in attrs:
+                setattr(m, a, type(a, (torch.nn.Module,), {"__init__": lambda self, *aa, **kw: torch.nn.Module.__init__(self)}))
+            sys.modules[name] = m
+    vq = importlib.machinery.SourceFileLoader("ref_vq_brain", str(REF / "models" / "vq_brain.py")).load_module()
+    torch.manual_seed(0)
+    net = vq.SoundStream(C=32, D=16, codebook_size=64, n_electrodes=16)
+    load_synth(net.encoder)
+    load_synth(net.decoder)
+    x = torch.from_numpy(synth.make_inputs(2, 40, 16))
+    x[1, 33:] = 0.0                                      # padded frames: excluded from the loss
+    e = net.encoder(x)
+    o = net.decoder(e)
+    loss = net.custom_l1_loss(o, x)
+    loss.backward()
+    idx = torch.from_numpy(np.random.default_rng(3).integers(0, 64, size=(2, 10)))
+    save("vq_conv_small", e=e.detach().numpy(), o=o.detach().numpy(), loss=np.array(float(loss)),
+         perp=np.array(float(net.calculate_perp(idx))), perp_idx=idx.numpy(),
+         **{"grad/encoder." + k: v.numpy() for k, v in grads_of(net.encoder).items()},
+         **{"grad/decoder." + k: v.numpy() for k, v in grads_of(net.decoder).items()})
+
+
 if __name__ == "__main__":
     if os.environ.get("FK_GOLDEN_ONLY") == "pipeline":
         pipeline_golden()
+    elif os.environ.get("FK_GOLDEN_ONLY") == "vq_conv_small":
+        vq_golden()
     else:
         main()
         pipeline_golden()
+        vq_golden()

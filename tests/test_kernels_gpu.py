@@ -503,3 +503,38 @@ def test_shadow_refresh_single_launch(K):
         assert E.shadow(ws) is sh[0] and E.shadow_swiglu(w1, w3) is sh[3]            # lookups, no re-pack
     finally:
         fa.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", [(3, 1, 1), (3, 1, 2), (4, 2, 1), (5, 1, 1), (2, 1, 1)])
+def test_im2col_col2im_causal(K, dtype, cfg):
+    """fk_im2col1d vs an explicit left-padded unfold; fk_col2im1d is its adjoint (<cols, g> == <x, col2im(g)>)."""
+    ks, stride, dil = cfg
+    B, T, C = 2, 11, 16
+    x = rnd(B * T, C, seed=4).view(B, T, C)
+    pad = dil * (ks - 1)
+    xp = torch.nn.functional.pad(q(x, dtype), (0, 0, pad, 0))
+    tout = (T - 1) // stride + 1
+    ref = torch.stack([torch.cat([xp[:, t * stride + k * dil] for k in range(ks)], -1) for t in range(tout)], 1).reshape(B * tout, ks * C)
+    cols = K.im2col1d(dev(x, dtype), ks, stride, dil)
+    assert torch.equal(cols.float().cpu(), ref)
+    g = rnd(B * tout, ks * C, seed=5)
+    dx = K.col2im1d(dev(g, torch.float32), B, T, C, ks, stride, dil)
+    lhs = (ref.double() * g.double()).sum()
+    rhs = (q(x, dtype).double() * dx.cpu().double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-3 * max(1.0, abs(float(lhs)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_elu_and_argmax(K, dtype):
+    x = rnd(37, 50, seed=6) * 3
+    xd = dev(x, dtype)
+    close(K.elu_fwd(xd), torch.nn.functional.elu(q(x, dtype)), dtype, atol32=1e-6)
+    dy = rnd(37, 50, seed=7)
+    ref = q(dy, dtype) * torch.where(q(x, dtype) > 0, torch.ones_like(x), torch.exp(q(x, dtype)))
+    close(K.elu_bwd(xd, dev(dy, dtype)), ref, dtype, atol32=1e-5)
+    a = q(x, dtype).clone()
+    a[3, 7] = a[3, 40] = 100.0                 # tie: first index wins
+    a[5] = -5.0                                # constant row
+    idx = K.argmax_rows(dev(a, dtype))
+    assert torch.equal(idx.cpu(), a.argmax(-1)) and int(idx[3]) == 7 and int(idx[5]) == 0
