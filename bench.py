@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true")
+    ap.add_argument("--all-timers", action="store_true", help="HIP-event timing of every kernel family (default: the roofline kernel family only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -139,6 +140,7 @@ def main():
     sync()
     if not args.no_timers:
         K.TIMERS = {}
+        K.TIMER_PREFIX = None if args.all_timers else "attn_"    # ~2000 event pairs per step cost ~1.2 ms; the roofline needs attention only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tu.train_step(model, pool[step % 2], opt, step, tcfg, sched)

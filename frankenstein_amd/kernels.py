@@ -17,6 +17,7 @@ Tensor = torch.Tensor
 
 # optional live instrumentation (bench.py): name -> list of (start_event, end_event) on the launch stream
 TIMERS = None
+TIMER_PREFIX = None   # e.g. "attn_": only kernels whose timer name starts with it are bracketed (an event pair costs ~0.6 us of GPU time)
 
 
 class _timed:
@@ -26,12 +27,13 @@ class _timed:
         self.name = name
 
     def __enter__(self):
-        if TIMERS is not None:
+        self.ev = None
+        if TIMERS is not None and (TIMER_PREFIX is None or self.name.startswith(TIMER_PREFIX)):
             self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.ev[0].record()
 
     def __exit__(self, *a):
-        if TIMERS is not None:
+        if self.ev is not None and TIMERS is not None:
             self.ev[1].record()
             TIMERS.setdefault(self.name, []).append(self.ev)
 
