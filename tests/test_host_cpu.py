@@ -167,3 +167,15 @@ def test_post_accumulate_hook_fires_for_directly_written_grads():
     (Direct.apply(Direct.apply(x, w)[:, :3] @ torch.randn(3, 4), w)).sum().backward()      # weight used twice
     assert len(fired) == 1
     assert torch.equal(fired[0], w.grad) and w.grad.abs().sum() > 0
+
+
+def test_soundstream_parameter_count_matches_notebook():
+    """notebooks_trainer/vq_brain_trainer.ipynb cell 1: SoundStream(C=256, D=64, codebook_size=1024, n_electrodes=512) has 5.61 M
+    parameters (the VQ layer of the reference holds buffers only, like the one here)."""
+    from frankenstein_amd.models import vq_brain as vq
+    m = vq.SoundStream(C=256, D=64, codebook_size=1024, n_electrodes=512)
+    assert round(sum(p.numel() for p in m.parameters()) / 1e6, 2) == 5.61
+    keys = set(m.state_dict())
+    assert {"encoder.layers.0.weight", "encoder.layers.2.layers.0.layers.0.weight", "encoder.layers.2.layers.6.bias",
+            "decoder.layers.2.layers.0.weight", "decoder.layers.6.bias"} <= keys
+    assert tuple(m.state_dict()["decoder.layers.2.layers.0.weight"].shape) == (256, 256, 4)      # ConvTranspose1d [Cin, Cout, K]

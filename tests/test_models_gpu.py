@@ -421,3 +421,19 @@ def test_soundstream_trains():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     g = net.encoder.layers[0].weight
     assert g.abs().sum() > 0
+
+
+def test_soundstream_notebook_shapes():
+    """notebooks_trainer/vq_brain_trainer.ipynb cell 1 smoke: [B, 768, 512] -> quantised [B, 192, 64], reconstruction [B, 768, 512]."""
+    import frankenstein_amd as fa
+    from frankenstein_amd.models import vq_brain as vq
+    fa.set_compute_dtype("bf16")
+    try:
+        m = vq.SoundStream(C=256, D=64, codebook_size=1024, n_electrodes=512).cuda().eval()
+        x = torch.randn(2, 768, 512, device="cuda")
+        idx, q = m.get_quantize_vectors(x)
+        assert tuple(idx.shape) == (2, 192) and tuple(q.shape) == (2, 192, 64)
+        loss, o = m(x)
+        assert tuple(o.shape) == (2, 768, 512) and torch.isfinite(loss)
+    finally:
+        fa.set_compute_dtype("fp32")
