@@ -96,14 +96,19 @@ __global__ __launch_bounds__(256) void norm_fwd_fast_kernel(const T* x, const fl
                                                              float* mean, float* rstd, int64_t rows, int dim, float eps, int kind) {
   constexpr int N = VecIO<T>::N, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane % LPR, sub = lane / LPR;
+  // gamma / beta: dim % N == 0 on this path, so a whole N-vector is in or out of range: 16-byte loads, one predicate per vector
+  // (48 branchy scalar loads per wave made the prologue as long as the three row iterations it served)
   float gm[MAXIT][N], bt[MAXIT][N];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int c = l * N + it * LPR * N;
+    const bool in = c < dim;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      gm[it][i] = (c + i < dim) ? gamma[c + i] : 0.0f;
-      bt[it][i] = (beta && c + i < dim) ? beta[c + i] : 0.0f;
+    for (int i = 0; i < N; i += 4) {
+      const f32x4 g4 = in ? *reinterpret_cast<const f32x4*>(gamma + c + i) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      const f32x4 b4 = (in && beta) ? *reinterpret_cast<const f32x4*>(beta + c + i) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gm[it][i + e] = g4[e]; bt[it][i + e] = b4[e]; }
     }
   }
   const float inv = 1.0f / dim;
@@ -214,7 +219,14 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const 
   for (int it = 0; it < MAXIT; ++it) {
     const int c = l * N + it * LPR * N;
 #pragma unroll
-    for (int i = 0; i < N; ++i) { ag[it][i] = 0.0f; ab[it][i] = 0.0f; gm[it][i] = (c + i < dim) ? gamma[c + i] : 0.0f; }
+    for (int i = 0; i < N; ++i) { ag[it][i] = 0.0f; ab[it][i] = 0.0f; }
+    const bool in = c < dim;                              // dim % N == 0: whole vectors in or out, 16-byte gamma loads
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+      const f32x4 g4 = in ? *reinterpret_cast<const f32x4*>(gamma + c + i) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gm[it][i + e] = g4[e];
+    }
   }
   const float inv = 1.0f / dim;
   const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const 
     const int64_t row = base + sub;
     const bool ok = row < rows;
     const float mu = (ok && kind == FK_NORM_LAYER) ? mean[row] : 0.0f, rs = ok ? rstd[row] : 0.0f;
-    float xv[MAXIT][N], gv[MAXIT][N];
+    float xv[MAXIT][N], gv[MAXIT][N], rv[MAXIT][N];
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const 
       if (ok && c < dim) {
         VecIO<T>::load(x + row * dim + c, xv[it]);
         VecIO<T>::load(dy + row * dim + c, gv[it]);
+        if (dres) VecIO<T>::load(dres + row * dim + c, rv[it]);      // issued with the other loads: its latency hides under the sums
       } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) { xv[it][i] = mu; gv[it][i] = 0.0f; }
@@ -248,11 +261,10 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const 
     for (int it = 0; it < MAXIT; ++it) {
       const int c = l * N + it * LPR * N;
       if (ok && c < dim) {
-        float o[N], rv[N];
-        if (dres) VecIO<T>::load(dres + row * dim + c, rv);
+        float o[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-          o[i] = rs * (gv[it][i] * gm[it][i] - c1 - xv[it][i] * c2) + (dres ? rv[i] : 0.0f);
+          o[i] = rs * (gv[it][i] * gm[it][i] - c1 - xv[it][i] * c2) + (dres ? rv[it][i] : 0.0f);
           ag[it][i] += gv[it][i] * xv[it][i];
           ab[it][i] += gv[it][i];
         }
@@ -361,12 +373,13 @@ int fk_norm_fwd(const void* x, const float* gamma, const float* beta, void* y, f
 #define FK_NF(TT, LPR, MI)                                                                                                 \
   do {                                                                                                                     \
     int64_t nbf = fk_cdiv(rows, 4 * (64 / LPR));                                                                           \
-    if (nbf > 4096) nbf = 4096;                                                                                            \
+    if (nbf > 2048) nbf = 2048;                                                                                            \
     hipLaunchKernelGGL((norm_fwd_fast_kernel<TT, LPR, MI>), dim3((unsigned)nbf), dim3(256), 0, s, (const TT*)x, gamma, beta, \
                        (TT*)y, mean, rstd, rows, (int)dim, eps, kind);                                                     \
   } while (0)
-  bool done = true;
-  if (dtype == FK_BF16) {
+  bool done = (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;       // the fast kernels read gamma / beta as 16-byte vectors
+  if (!done) {
+  } else if (dtype == FK_BF16) {
     if (dim <= per16) FK_NF(bf16_t, 16, 1); else if (dim <= 2 * per16) FK_NF(bf16_t, 16, 2); else if (dim <= 3 * per16) FK_NF(bf16_t, 16, 3);
     else if (dim <= 4 * per16) FK_NF(bf16_t, 16, 4); else if (dim <= 2 * per64) FK_NF(bf16_t, 64, 2); else if (dim <= 4 * per64) FK_NF(bf16_t, 64, 4);
     else done = false;
@@ -406,7 +419,8 @@ int fk_norm_bwd(const void* dy, const void* x, const float* gamma, const float* 
   FK_CHECK_ARG(dy && x && gamma && rstd && dx, "fk_norm_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int per16 = 16 * vec, per64 = 64 * vec;
-  const bool fits = (dtype == FK_BF16 ? dim <= 4 * per64 : dim <= 4 * per64) && (size_t)8 * dim * sizeof(float) <= 65536;
+  const bool fits = (dtype == FK_BF16 ? dim <= 4 * per64 : dim <= 4 * per64) && (size_t)8 * dim * sizeof(float) <= 65536 &&
+                    ((uintptr_t)gamma & 15) == 0;     // the fused kernel reads gamma as 16-byte vectors
   if (fits) {
     // fused sweep: dx + per-block dgamma/dbeta partials
     const bool want = dgamma || dbeta;
