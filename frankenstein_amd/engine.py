@@ -154,8 +154,10 @@ def _shadow_entry(key, params) -> "_Shadow":
         ent = None
     if ent is None:
         ent = _SHADOWS[key] = _Shadow()
-        ent.params = tuple(weakref.ref(p) for p in params)
-        ent.ptrs = tuple(p.data_ptr() for p in params)
+        # a view (space_embedding.view(C, d), ...) is tracked through its base: the view object dies with the call
+        owners = [p._base if p._base is not None else p for p in params]
+        ent.params = tuple(weakref.ref(o) for o in owners)
+        ent.ptrs = tuple(o.data_ptr() for o in owners)
         ent.dtype = _COMPUTE_DTYPE
     return ent
 
