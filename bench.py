@@ -91,6 +91,19 @@ def cpu_baseline(steps=2):
                       f"fwd+bwd+clip+AdamW, {best:.2f} s/step"}
 
 
+def mfma_util_pmc():
+    """MFMA-pipe busy fraction of the whole step and of the roofline kernels from the committed rocprofv3 counter pass
+    (profiles/r01_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); None if absent."""
+    try:
+        pm = json.load(open(ROOT / "profiles" / "r01_pmc_mfma_util.json"))
+        ks = pm["kernels"]
+        pick = lambda frag: next((round(v["mfma_util_pct"], 1) for k, v in ks.items() if frag in k), None)
+        return {"whole_step_pct": round(pm["whole_trace"]["mfma_util_pct"], 1), "attn_bwd_dkdv_pct": pick("attn_bwd_dkdv"),
+                "attn_bwd_dq_pct": pick("attn_bwd_dq"), "executed_mfma_tflops": round(pm["whole_trace"]["mfma_tflops"], 1)}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +204,7 @@ def main():
                        "electrodes": Cn, "parallelism": f"dp{world}", "weights": "random-init (seed 42)"},
             "roofline": roof,
             "step_roofline": {"bound": "mfma", "achieved": round(value / world * FLOP_PER_FRAME / 1e12, 2),
+                              "mfma_util_pmc": mfma_util_pmc(),
                               "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                               "frac": round(value / world * FLOP_PER_FRAME / MFMA_PEAK_BF16, 4),
                               "note": "whole step per GPU: frames/s x 1.8173 GFLOP/frame (SURVEY §8d)"},
