@@ -79,6 +79,10 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     // column-of-rows b128 writes and the row-sweep b128 reads; 4 waves x 16 KiB = the 64 KiB already allocated.
     auto eoff = [](int row, int colf) { return row * 256 + ((((colf >> 2) ^ (row & 15)) << 4) | ((colf & 3) << 2)); };
     if (sync) __syncthreads();                      // all waves finished reading the operand tiles
+    // The slice is reused by back-to-back calls (one per 32-row group): the previous call's last ds_read_b128s must have
+    // returned before this call's ds_write_b128s are issued.  Without the wait, rows 30/31 of a group (the last lane groups of
+    // the last pass) occasionally came back with the NEXT group's values — found by a run-to-run determinism check at full size.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -393,14 +397,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(NtArgs p) {
       }
       __syncthreads();   // drains this wave's LDS-DMA (vmcnt) and orders every wave's reads / DMA writes
     }
-    // Both buffers are idle: the next tile's first k-stage goes into buffer 0 now, so its DMA latency (and this tile's store
-    // drain) run under the epilogue, which stages its two 32-row halves through this wave's 8 KiB slice of buffer 1.
-    if (tile + nbx < t_end) { set_src(tile + nbx); stage(0, 0); }
+    // Epilogue: two 32-row halves through this wave's 8 KiB slice of buffer 1, THEN the next tile's first k-stage into buffer 0.
+    // (Issuing that DMA before the epilogue bought nothing measurable and made the RoPE epilogue return a few wrong elements per
+    // ~10^8 — rows 30/31 of a group, run-to-run different; tools/determinism_probe.py and the full-size test guard this.)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
       nt_epilogue<T, TO, false, 1>(p, sub, smem + 2 * TILE_BYTES + wave * 8192, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, false);
     }
+    if (tile + nbx < t_end) { set_src(tile + nbx); stage(0, 0); }
   }
 }
 
@@ -480,14 +485,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
       }
       __syncthreads();
     }
-    // prefetch the next tile's first k-stage into buffer 0 under the epilogue; the epilogue stages 32-row slices of the
-    // wave tile through this wave's 8 KiB of buffer 1
-    if (tile + nbx < t_end) { set_src(tile + nbx); stage(0, 0); }
+    // the epilogue stages 32-row slices of the wave tile through this wave's 8 KiB of buffer 1; the next tile's first k-stage
+    // is issued after it (see gemm_nt_glds_kernel)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
       nt_epilogue<T, TO, true, 1>(p, sub, smem + STAGE + wave * 8192, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
     }
+    if (tile + nbx < t_end) { set_src(tile + nbx); stage(0, 0); }
   }
 }
 

@@ -437,3 +437,44 @@ def test_soundstream_notebook_shapes():
         assert tuple(o.shape) == (2, 768, 512) and torch.isfinite(loss)
     finally:
         fa.set_compute_dtype("fp32")
+
+
+def test_cfg2_full_size_properties():
+    """BASELINE configs[1] at its full size (B = 32, T = 600 -> N = 6144 tokens, bf16) through size-independent properties:
+    * samples are independent: permuting the batch permutes the predictions bit for bit;
+    * the encoder is block-causal in time: changing the frames of patches >= 12 leaves the tokens of patches < 12 bit-identical
+      and changes later ones (build_advanced_causal_mask, models/brainformer.py:93-111, at the full 6144 x 6144 extent);
+    * one optimiser step of the 2-rank-style half batches equals the full-batch mean gradient (linearity of the mean loss)."""
+    import bench
+    from frankenstein_amd.models import brainformer as bf
+    fa.set_compute_dtype("bf16")
+    try:
+        m, cfg = bench.cfg2_model("bf16")
+        bench.init_weights(m)
+        m.cuda()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        x = torch.randn(32, 600, 256, device="cuda", generator=g)
+        y = torch.randn(32, 32, 128, device="cuda", generator=g)
+        with torch.no_grad():
+            _, pred = m(x, y)
+            perm = torch.randperm(32, device="cuda", generator=g)
+            _, pred_p = m(x[perm].contiguous(), y[perm].contiguous())
+            assert torch.equal(pred_p, pred[perm])
+            enc = m.encoder(x)                                   # [32, 6144, 384], token = patch * 256 + electrode
+            x2 = x.clone()
+            x2[:, 12 * 25:] += 1.0
+            enc2 = m.encoder(x2)
+            assert torch.equal(enc2[:, :12 * 256], enc[:, :12 * 256])
+            assert not torch.equal(enc2[:, 12 * 256:13 * 256], enc[:, 12 * 256:13 * 256])
+        def grads(xs, ys):
+            for p in m.parameters():
+                p.grad = None
+            loss, _ = m(xs, ys)
+            loss.backward()
+            return torch.cat([p.grad.reshape(-1).float() for p in m.parameters() if p.grad is not None])
+        gfull = grads(x, y)
+        ghalf = 0.5 * (grads(x[:16].contiguous(), y[:16].contiguous()) + grads(x[16:].contiguous(), y[16:].contiguous()))
+        rel = float((gfull - ghalf).norm() / gfull.norm())
+        assert rel < 2e-2, rel                                    # bf16 activations: split batches round differently
+    finally:
+        fa.set_compute_dtype("fp32")
