@@ -786,8 +786,51 @@ __global__ void reduce_slabs_kernel(const float* ws, float* C, int64_t ldc, int 
 
 // ------------------------------------------------------------------------------------------------ colsum
 // out[c] (+)= sum_r X[r, c]; two stages through a [nblk, cols] fp32 workspace (deterministic).
+// Stage 1: a block owns rows_per_blk rows; thread = (16-byte column vector, row group): 16-byte loads, the row groups of a block are
+// combined through LDS.  Stage 2: 64 columns x 4 partial groups per block.
 template <typename T>
-__global__ void colsum_partial_kernel(const T* X, int64_t ld, float* part, int rows, int cols, int rows_per_blk) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* X, int64_t ld, float* part, int rows, int cols, int rows_per_blk) {
+  constexpr int N = 16 / sizeof(T);
+  __shared__ float red[256 * N];
+  const int r0 = blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  const int cvt = (cols + N - 1) / N;                     // column vectors in a row (cols % N == 0 on the vector path)
+  {
+    const int cv0 = blockIdx.x * 256;                    // grid.x walks 256-vector column chunks
+    const int cvn = min(256, cvt - cv0), groups = 256 / cvn;
+    const int vec = threadIdx.x % cvn, grp = threadIdx.x / cvn;
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = 0.0f;
+    if (grp < groups) {
+      const T* p = X + (int64_t)(cv0 + vec) * N;
+      for (int r = r0 + grp; r < r1; r += groups) {
+        if constexpr (sizeof(T) == 2) {
+          bf16x8 v = *reinterpret_cast<const bf16x8*>(p + (int64_t)r * ld);
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] += (float)v[e];
+        } else {
+          f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)r * ld);
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] += v[e];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < N; ++e) red[threadIdx.x * N + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < cvn) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        float sm = 0.0f;
+        for (int g2 = 0; g2 < groups; ++g2) sm += red[(g2 * cvn + threadIdx.x) * N + e];       // fixed order: deterministic
+        part[(int64_t)blockIdx.y * cols + (cv0 + threadIdx.x) * N + e] = sm;
+      }
+    }
+  }
+}
+template <typename T>
+__global__ void colsum_partial_scalar_kernel(const T* X, int64_t ld, float* part, int rows, int cols, int rows_per_blk) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   const int r0 = blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
@@ -795,12 +838,18 @@ __global__ void colsum_partial_kernel(const T* X, int64_t ld, float* part, int r
   for (int r = r0; r < r1; ++r) s += to_f32<T>(X[(int64_t)r * ld + c]);
   part[(int64_t)blockIdx.y * cols + c] = s;
 }
-__global__ void colsum_final_kernel(const float* part, float* out, int cols, int nblk, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, float* out, int cols, int nblk, int accumulate) {
+  __shared__ float red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   float s = 0.0f;
-  for (int k = 0; k < nblk; ++k) s += part[(int64_t)k * cols + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < cols)
+    for (int k = g; k < nblk; k += 4) s += part[(int64_t)k * cols + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+    const float t = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 int tn_splits(int64_t M, int64_t N1, int64_t N2, int bkm) {
@@ -964,12 +1013,19 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
   const int nb = colsum_blocks(rows);
   FK_CHECK_ARG(workspace && workspace_bytes >= (size_t)nb * cols * sizeof(float), "fk_colsum: workspace too small");
   const int rpb = (int)fk_cdiv(rows, nb);
-  dim3 grid((unsigned)fk_cdiv(cols, 256), (unsigned)nb), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == FK_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)X, ld, (float*)workspace, (int)rows, (int)cols, rpb);
-  else hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, block, 0, s, (const float*)X, ld, (float*)workspace, (int)rows, (int)cols, rpb);
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  if (cols % vec == 0 && ld % vec == 0 && ((uintptr_t)X & 15) == 0) {
+    dim3 grid((unsigned)fk_cdiv(fk_cdiv(cols, vec), 256), (unsigned)nb), block(256);
+    if (dtype == FK_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)X, ld, (float*)workspace, (int)rows, (int)cols, rpb);
+    else hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, block, 0, s, (const float*)X, ld, (float*)workspace, (int)rows, (int)cols, rpb);
+  } else {
+    dim3 grid((unsigned)fk_cdiv(cols, 256), (unsigned)nb), block(256);
+    if (dtype == FK_BF16) hipLaunchKernelGGL(colsum_partial_scalar_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)X, ld, (float*)workspace, (int)rows, (int)cols, rpb);
+    else hipLaunchKernelGGL(colsum_partial_scalar_kernel<float>, grid, block, 0, s, (const float*)X, ld, (float*)workspace, (int)rows, (int)cols, rpb);
+  }
   FK_CHECK_LAUNCH("fk_colsum(partial)");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)fk_cdiv(cols, 256)), block, 0, s, (const float*)workspace, out, (int)cols, nb, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)fk_cdiv(cols, 64)), dim3(256), 0, s, (const float*)workspace, out, (int)cols, nb, accumulate);
   FK_CHECK_LAUNCH("fk_colsum(final)");
   return FK_OK;
 }
