@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libfranken_hip.so"
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_optim.hip", "pipeline.hip", "conv.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_optim.hip", "pipeline.hip", "conv.hip", "decode.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950 has a unified file), which removes the
 # v_accvgpr_read/write traffic between the matrix results and the softmax / epilogue VALU code.

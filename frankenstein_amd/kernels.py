@@ -425,6 +425,36 @@ def add2d_(dst: Tensor, src: Tensor) -> Tensor:
     return dst
 
 
+# ------------------------------------------------------------------------------------------- decode step (device-side position)
+def gpt_embed_step(idx: Tensor, wte: Tensor, wpe: Tensor, pos: Tensor, dtype: torch.dtype) -> Tensor:
+    """x[b] = wte[idx[b]] + wpe[pos[0]]; idx int64 [B], pos int32 [1] on the device."""
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and pos.dtype == torch.int32 and pos.numel() == 1
+    assert wte.dtype == torch.float32 and wpe.dtype == torch.float32 and wte.is_contiguous() and wpe.is_contiguous()
+    B, dim = idx.numel(), wte.shape[1]
+    out = torch.empty((B, dim), dtype=dtype, device=idx.device)
+    call("fk_gpt_embed_step", idx.data_ptr(), wte.data_ptr(), wpe.data_ptr(), pos.data_ptr(), out.data_ptr(), B, dim, wte.shape[0],
+         fk_dtype(dtype), _stream())
+    return out
+
+
+def kv_append_(qkv: Tensor, kv: Tensor, pos: Tensor) -> None:
+    """kv[b, pos[0], :] = qkv[b, d:3d]; qkv [B, 3d] contiguous, kv [B, Tmax, 2d] contiguous."""
+    B, d3 = qkv.shape
+    assert qkv.is_contiguous() and kv.is_contiguous() and kv.shape[0] == B and kv.shape[2] * 3 == d3 * 2 and kv.dtype == qkv.dtype
+    call("fk_kv_append", qkv.data_ptr(), kv.data_ptr(), pos.data_ptr(), B, d3 // 3, kv.shape[1], fk_dtype(qkv), _stream())
+
+
+def attn_decode(qkv: Tensor, kv: Tensor, pos: Tensor, n_head: int) -> Tensor:
+    """one causal query per sample against the cache rows 0..pos[0]: q = qkv[:, :d] -> o [B, d]."""
+    B, d3 = qkv.shape
+    d = d3 // 3
+    D = d // n_head
+    out = torch.empty((B, d), dtype=qkv.dtype, device=qkv.device)
+    call("fk_attn_decode", qkv.data_ptr(), qkv.stride(0), kv.data_ptr(), kv.stride(0), kv.stride(1), out.data_ptr(), d, pos.data_ptr(),
+         B, n_head, D, 1.0 / math.sqrt(D), fk_dtype(qkv), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------- conv (VQ-VAE tokenizer)
 def im2col1d(x: Tensor, ksize: int, stride: int = 1, dil: int = 1) -> Tensor:
     """x [B, T, C] -> cols [B * Tout, ksize * C] with the causal left padding dil * (ksize - 1); Tout = (T - 1) // stride + 1."""

@@ -115,6 +115,26 @@ class Block(nn.Module):
         return x2.view(B, t, d)
 
 
+def _bias(lin):
+    return None if lin.bias is None else E.shadow([lin.bias])
+
+
+def _block_forward_decode(self, x, kv, pos):
+    """One new token per sample with the position in a device int32 (graph-capturable): x [B, d], kv [B, Tmax, 2d]."""
+    at, ml = self.attn, self.mlp
+    h, _, _ = K.norm_fwd(x, self.ln_1.weight.detach(), None if self.ln_1.bias is None else self.ln_1.bias.detach(), self.ln_1.eps)
+    qkv = K.gemm_nt(h, E.shadow([at.c_attn.weight]), _bias(at.c_attn))
+    K.kv_append_(qkv, kv, pos)
+    o = K.attn_decode(qkv, kv, pos, at.n_head)
+    x = K.gemm_nt(o, E.shadow([at.c_proj.weight]), _bias(at.c_proj), residual=x)
+    h, _, _ = K.norm_fwd(x, self.ln_2.weight.detach(), None if self.ln_2.bias is None else self.ln_2.bias.detach(), self.ln_2.eps)
+    a = K.gemm_nt(h, E.shadow([ml.c_fc.weight]), _bias(ml.c_fc))
+    return K.gemm_nt(K.gelu_fwd(a), E.shadow([ml.c_proj.weight]), _bias(ml.c_proj), residual=x)
+
+
+Block.forward_decode = _block_forward_decode
+
+
 @dataclass
 class GPTConfig:
     block_size: int = 1024
@@ -282,31 +302,84 @@ class GPT(nn.Module):
         return logits, pos + t
 
     @torch.no_grad()
-    def generate(self, idx, max_new_tokens, prefix=None, temperature=1.0, top_k=None, use_cache=True):
+    def _decode_logits_dev(self, cur, cache, pos):
+        """last-position logits [B, V] for the tokens `cur` [B] at device position pos (int32[1]); appends to the caches."""
+        x = K.gpt_embed_step(cur, self.transformer.wte.weight.detach(), self.transformer.wpe.weight.detach(), pos, E.compute_dtype())
+        for li, block in enumerate(self.transformer.h):
+            x = block.forward_decode(x, cache[li], pos)
+        ln = self.transformer.ln_f
+        h, _, _ = K.norm_fwd(x, ln.weight.detach(), None if ln.bias is None else ln.bias.detach(), ln.eps)
+        V = self.config.vocab_size
+        return K.gemm_nt(h, E.shadow([self.lm_head.weight], pad_n=(V + 7) // 8 * 8), out_dtype=torch.float32)[:, :V]
+
+    @staticmethod
+    def _sample(logits, temperature, top_k):
+        logits = logits.float() / temperature
+        if top_k is not None:
+            v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+            logits = logits.masked_fill(logits < v[:, -1:], -float('Inf'))
+        return torch.multinomial(torch.softmax(logits, dim=-1), num_samples=1)
+
+    @torch.no_grad()
+    def generate(self, idx, max_new_tokens, prefix=None, temperature=1.0, top_k=None, use_cache=True, use_graph=None):
         """Sampling loop of the reference (models/gpt2_model.py:328-353: temperature, top-k crop, softmax, multinomial; returns
         the first sample's ids).  With use_cache (default) the prefix + prompt are run once and every new token is one
-        incremental step against per-layer key/value caches; when the sequence would outgrow block_size the reference's
-        crop-and-re-forward path is used instead."""
+        incremental step against per-layer key/value caches; with use_graph (default: on from 64 new tokens, where the one-off
+        capture has paid for itself)
+        that step — embedding, blocks, head AND the sampling — reads its position from the device and is captured once as a
+        hipGraph that is replayed per token (the step is launch-bound: ~25 small kernels).  When the sequence would outgrow
+        block_size the reference's crop-and-re-forward path is used instead."""
         B, t0 = idx.shape
         t_ctx = 0 if prefix is None else prefix.shape[1]
         total = t_ctx + t0 + max_new_tokens
         cached = use_cache and total <= self.config.block_size and max_new_tokens > 0
+        if use_graph is None:
+            use_graph = max_new_tokens >= 64
         if cached:
             d = self.config.n_embd
             cache = [torch.empty((B, total, 2 * d), dtype=E.compute_dtype(), device=idx.device) for _ in self.transformer.h]
             logits, pos = self._cached_logits(idx, cache, 0, None if prefix is None else _prep(prefix))
+            if use_graph and idx.is_cuda:
+                return self._generate_graph(idx, logits, cache, pos, max_new_tokens, temperature, top_k)
         for it in range(max_new_tokens):
             if cached:
                 if it > 0:
                     logits, pos = self._cached_logits(idx[:, -1:], cache, pos)
-                logits = logits.float() / temperature
             else:
                 idx_cond = idx if idx.size(1) <= self.config.block_size else idx[:, -self.config.block_size:]
                 _, lg = self(idx_cond, prefix=prefix)
-                logits = lg[:, -1, :].float() / temperature
-            if top_k is not None:
-                v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
-                logits[logits < v[:, [-1]]] = -float('Inf')
-            probs = torch.softmax(logits, dim=-1)
-            idx = torch.cat((idx, torch.multinomial(probs, num_samples=1)), dim=1)
+                logits = lg[:, -1, :]
+            idx = torch.cat((idx, self._sample(logits, temperature, top_k)), dim=1)
         return idx[0]
+
+    @torch.no_grad()
+    def _generate_graph(self, idx, logits0, cache, pos0, max_new_tokens, temperature, top_k):
+        B, dev = idx.shape[0], idx.device
+        out = torch.empty((B, max_new_tokens), dtype=torch.int64, device=dev)
+        cur = self._sample(logits0, temperature, top_k).view(B).contiguous()
+        out[:, 0] = cur
+        pos = torch.tensor([pos0], dtype=torch.int32, device=dev)
+        col = torch.ones(1, dtype=torch.int64, device=dev)
+
+        def step():
+            nxt = self._sample(self._decode_logits_dev(cur, cache, pos), temperature, top_k)
+            cur.copy_(nxt.view(B))
+            out.index_copy_(1, col, nxt)
+            col.add_(1)
+            pos.add_(1)
+
+        n_eager = min(2, max_new_tokens - 1)            # warm-up (allocator, lazy shadows) before the capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(n_eager):
+                step()
+            remaining = max_new_tokens - 1 - n_eager
+            if remaining > 0:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):      # records the step, does not run it
+                    step()
+                for _ in range(remaining):
+                    graph.replay()
+        torch.cuda.current_stream().wait_stream(side)
+        return torch.cat((idx, out), dim=1)[0]

@@ -141,6 +141,17 @@ int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
 /* y = a + b (same dtype) */
 int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
 
+/* ---- single-token decode step with the position on the DEVICE (`pos`: int32[1]), so one captured hipGraph serves every new token
+ * of GPT.generate (models/gpt2_model.py:328-353; the reference re-forwards the whole sequence per token).
+ * fk_gpt_embed_step: out[b,:] = wte[idx[b],:] + wpe[*pos,:].   fk_kv_append: kv[b, *pos, :] = qkv[b, d:3d] (kv [B, tmax, 2d]).
+ * fk_attn_decode: o[b,h,:] = softmax_j(q[b,h,:] . k[b,j,h,:] * scale) v[b,j,h,:] over j = 0..*pos; k at kv + b*kv_bs + j*kv_rs + h*D,
+ * v = k + H*D; strides in elements.                                                                                    */
+int fk_gpt_embed_step(const int64_t* idx, const float* wte, const float* wpe, const int32_t* pos, void* out, int64_t B, int64_t dim,
+                      int64_t vocab, int dtype, void* stream);
+int fk_kv_append(const void* qkv, void* kv, const int32_t* pos, int64_t B, int64_t d, int64_t tmax, int dtype, void* stream);
+int fk_attn_decode(const void* q, int64_t q_bs, const void* kv, int64_t kv_bs, int64_t kv_rs, void* out, int64_t o_bs, const int32_t* pos,
+                   int64_t B, int64_t H, int64_t D, float scale, int dtype, void* stream);
+
 /* ---- VQ-VAE tokenizer convolutions (models/vq_brain.py), channels-last [B, T, C], causal left padding dil*(K-1):
  * fk_im2col1d: cols[b, t, k, :] = x[b, t*stride + k*dil - pad, :] (zeros outside), Tout = (T-1)/stride + 1, so that
  *   CausalConv1d (:22-28) = fk_gemm_nt(cols, W') with W'[o, k*Cin + c] = W[o, c, k], and CausalConvTranspose1d(kernel 2s,

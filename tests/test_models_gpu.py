@@ -152,6 +152,34 @@ def test_gpt_generate_greedy_matches_reference(golden, use_cache):
         assert g.generate(idx[:, :4].cuda(), 5, prefix=prefix.cuda(), top_k=1).cpu().tolist() == outs[0].cpu().tolist()
 
 
+def test_gpt_generate_graph_matches_reference(golden):
+    """The hipGraph-captured decode step (position read on the device: fk_gpt_embed_step / fk_kv_append / fk_attn_decode, sampling
+    inside the graph) reproduces the reference's greedy tokens, and its per-step logits equal the host-position cached path."""
+    z = golden("gpt_generate")
+    cfgo, prefix, tk, idx = C.gpt_small(True)
+    g = load_synth(mk_gpt(cfgo)).eval()
+    start = torch.from_numpy(z["start"]).cuda()
+    pf = prefix[:1].cuda()
+    out = g.generate(start.clone(), max_new_tokens=8, prefix=pf, top_k=1, use_graph=True)
+    assert out.cpu().tolist() == z["tokens"].tolist()
+    out3 = g.generate(idx[:, :4].cuda(), 12, prefix=prefix.cuda(), top_k=1, use_graph=True)          # batched, 12 tokens
+    ref3 = g.generate(idx[:, :4].cuda(), 12, prefix=prefix.cuda(), top_k=1, use_graph=False)
+    assert out3.cpu().tolist() == ref3.cpu().tolist()
+    # device-position step == host-position step on the same caches
+    from frankenstein_amd import engine as E
+    from frankenstein_amd.models.brainformer import _prep
+    d, total = cfgo.n_embd, 5 + 4 + 4
+    mk = lambda: [torch.zeros((3, total, 2 * d), dtype=E.compute_dtype(), device="cuda") for _ in g.transformer.h]
+    ca, cb = mk(), mk()
+    la, pos = g._cached_logits(idx[:, :4].cuda(), ca, 0, _prep(prefix.cuda()))
+    g._cached_logits(idx[:, :4].cuda(), cb, 0, _prep(prefix.cuda()))
+    tok = la.argmax(-1)
+    la2, _ = g._cached_logits(tok[:, None].contiguous(), ca, pos)
+    lb2 = g._decode_logits_dev(tok.contiguous(), cb, torch.tensor([pos], dtype=torch.int32, device="cuda"))
+    np.testing.assert_allclose(lb2.float().cpu().numpy(), la2.float().cpu().numpy(), atol=2e-5)
+    assert torch.equal(ca[0][:, :pos + 1], cb[0][:, :pos + 1])
+
+
 def build_franky():
     from frankenstein_amd.models.notebook_models import BrainEncoder, Franky
     bcfg, gcfg, x, tok = C.cfg1()

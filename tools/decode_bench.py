@@ -10,11 +10,13 @@ fa.set_compute_dtype("bf16")
 g = GPT(GPTConfig(block_size=1024, vocab_size=50257, n_layer=2, n_head=4, n_embd=128, dropout=0.0, bias=True)).cuda().eval()
 prefix = torch.randn(1, 32, 128, device="cuda")
 start = torch.full((1, 1), 50256, dtype=torch.long, device="cuda")
-for n_new in (25, 200):
-    for cache in (True, False):
-        g.generate(start, 4, prefix=prefix, top_k=1, use_cache=cache)
+modes = {"re-forward": dict(use_cache=False), "kv-cache": dict(use_cache=True, use_graph=False),
+         "kv-cache + hipGraph": dict(use_cache=True, use_graph=True)}
+for n_new in (25, 200, 900):
+    for name, kw in modes.items():
+        g.generate(start, 4, prefix=prefix, top_k=1, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(3):
-            g.generate(start, n_new, prefix=prefix, top_k=1, use_cache=cache)
+            g.generate(start, n_new, prefix=prefix, top_k=1, **kw)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-        print(f"{n_new:4d} new tokens, {'kv-cache ' if cache else 're-forward'}: {dt * 1e3:8.1f} ms  ({n_new / dt:7.0f} tokens/s)")
+        print(f"{n_new:4d} new tokens, {name:20s}: {dt * 1e3:8.1f} ms  ({n_new / dt:7.0f} tokens/s)")
