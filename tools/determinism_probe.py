@@ -67,7 +67,19 @@ checks["gemm_nt_rope qkv vs rocBLAS + rotation"] = (K.gemm_nt_rope(x, w_qkv, Non
 for name, (out, ref) in checks.items():
     e = rel_err(out, ref)
     print(f"{name:40s} {'OK' if e < 2e-2 else 'MISMATCH'}  max err / max |ref| = {e:.2e}", flush=True)
-del checks, h13r, hr, qr, qq, rot, xf, dyf
+# bf16 LDS-DMA attention kernels at the full N = 6144 against the fp32 kernels (a different code path, itself pinned to the reference at
+# this N by the cfg2_b1 golden) on the same bf16-representable inputs, 2 samples
+def attn_pair(dtype):
+    qs, ks, vs, dos = (t[:2].to(dtype).contiguous() for t in (q, k, v, do))
+    oo, ll = K.attn_fwd(qs, ks, vs, mask)
+    dq_, dk_, dv_ = torch.empty_like(qs), torch.empty_like(ks), torch.empty_like(vs)
+    K.attn_bwd(qs, ks, vs, oo, dos, ll, dq_, dk_, dv_, mask)
+    return oo, dq_, dk_, dv_
+lo, hi = attn_pair(torch.bfloat16), attn_pair(torch.float32)
+for nm, a_, b_ in zip(("attn_fwd o", "attn_bwd dq", "attn_bwd dk", "attn_bwd dv"), lo, hi):
+    e = rel_err(a_, b_.float())
+    print(f"{nm + ' bf16 vs fp32 kernels, N=6144':40s} {'OK' if e < 3e-2 else 'MISMATCH'}  max err / max |ref| = {e:.2e}", flush=True)
+del checks, h13r, hr, qr, qq, rot, xf, dyf, lo, hi
 torch.cuda.empty_cache()
 
 for name, f in cases.items():
