@@ -32,6 +32,9 @@ cases = {
     "gemm_nt_dswiglu": lambda: K.gemm_nt_dswiglu(dy, w2t, h13),
     "gemm_nt d_up": lambda: K.gemm_nt(dh13, w13t),
     "gemm_nt d_qkv": lambda: K.gemm_nt(qkv, w_qkvt),
+    "gemm_nt fp32 out": lambda: K.gemm_nt(x[:16384], w_qkv, out_dtype=torch.float32),
+    "gemm_nt fp32 out 256-tile": lambda: K.gemm_nt(x[:16384], w13, out_dtype=torch.float32),
+    "gemm_nt bias+res": lambda: K.gemm_nt(x, w_proj, gam.bfloat16(), residual=dy),
     "gemm_tn dW_qkv": lambda: K.gemm_tn(qkv, x),
     "gemm_tn dW_up": lambda: K.gemm_tn(dh13, x),
     "gemm_tn dW_down": lambda: K.gemm_tn(dy, gg),
