@@ -507,3 +507,31 @@ def test_cfg2_full_size_properties():
         assert rel < 2e-2, rel                                    # bf16 activations: split batches round differently
     finally:
         fa.set_compute_dtype("fp32")
+
+
+def test_bf16_odd_shapes_train_steps():
+    """bf16 training steps at shapes that are not multiples of any tile (B = 3, 19 patches x 256 electrodes = 4864 tokens, 5 heads x 64):
+    finite, decreasing loss, run-to-run identical first step."""
+    from frankenstein_amd.models import brainformer as bf
+    from frankenstein_amd.utils import train_utils as tu
+    fa.set_compute_dtype("bf16")
+    try:
+        enc = bf.MAEConfig(window_size=475, n_electrodes=256, patch_size=25, dim=320, n_layers=2, head_dim=64, hidden_dim=840,
+                           n_heads=5, n_kv_heads=5)
+        cfg = bf.Config(encoder=enc, n_output_tokens=9, output_dim=70, dim=320, n_layers=1, head_dim=64, hidden_dim=328,
+                        n_heads=5, n_kv_heads=5)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.randn(3, 475, 256, device="cuda", generator=g)
+        y = torch.randn(3, 9, 70, device="cuda", generator=g)
+        firsts = []
+        for rep in range(2):
+            torch.manual_seed(0)
+            m = bf.BrainFormer(cfg).cuda()
+            opt = tu.FusedAdamW(m, lr=2e-3, weight_decay=0.0, grad_clip=1.0)
+            tc = tu.TrainConfig(mixed_precision=True, use_scheduler=False, learning_rate=2e-3)
+            losses = [float(tu.train_step(m, (x, y, None), opt, s, tc)) for s in range(6)]
+            assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+            firsts.append((losses[0], opt.arena.flat.detach().clone()))
+        assert firsts[0][0] == firsts[1][0] and torch.equal(firsts[0][1], firsts[1][1])
+    finally:
+        fa.set_compute_dtype("fp32")
