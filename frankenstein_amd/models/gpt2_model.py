@@ -383,3 +383,50 @@ class GPT(nn.Module):
                     graph.replay()
         torch.cuda.current_stream().wait_stream(side)
         return torch.cat((idx, out), dim=1)[0]
+
+    @torch.no_grad()
+    def generate_beam_search(self, idx, max_new_tokens, prefix, temperature=1.0, topk=20, beam_width=5):
+        """Stochastic beam search of the reference (models/gpt2_model.py:355-416): every step each of the `beam_width` beams draws
+        `beam_width` continuations WITHOUT replacement from its `topk` most likely tokens, the `beam_width` best-scoring
+        (cumulative log-probability) of the beam_width^2 candidates survive; returns the best beam's ids.  Batch size 1.
+        Host-side bookkeeping around the kernel forward (one batched forward of all beams per step)."""
+        if topk is None:
+            topk = 2 * beam_width
+        self.eval()
+        beams = idx.repeat(beam_width, 1)
+        scores = torch.zeros(beam_width, device=idx.device)
+        prefix = prefix.expand(beam_width, -1, -1)
+        for _ in range(max_new_tokens):
+            _, logits = self(beams, prefix=prefix.contiguous())
+            logp = torch.log_softmax(logits[:, -1, :].float() / temperature, dim=-1)
+            top_lp, top_ix = logp.topk(topk, dim=-1)
+            picks = torch.multinomial(top_lp.exp(), beam_width, replacement=False)           # [beam, beam_width] indices into top-k
+            cand_score = (scores[:, None] + top_lp.gather(1, picks)).reshape(-1)
+            cand_tok = top_ix.gather(1, picks).reshape(-1)
+            cand_beam = torch.arange(beam_width, device=idx.device).repeat_interleave(beam_width)
+            order = torch.sort(cand_score, descending=True, stable=True).indices[:beam_width]
+            beams = torch.cat((beams[cand_beam[order]], cand_tok[order, None]), dim=1)
+            scores = cand_score[order]
+        return beams[scores.argmax()]
+
+    @torch.no_grad()
+    def beam_search(self, idx, max_new_tokens, prefix, temperature=1.0, topk=20, beam_width=3):
+        """Deterministic beam search of the reference (models/gpt2_model.py:419-454), including its quirk: the running context
+        `idx` is shared by all beams and grows by every beam's last token in turn (it is not forked per beam), so the scores are
+        those of that merged sequence.  Returns the token list of the best entry [idx[0, 0], t1, t2, ...].  Batch size 1."""
+        self.eval()
+        _, logits = self(idx, prefix=prefix)
+        lp, ix = torch.topk(torch.log_softmax(logits[:, -1, :].float(), dim=-1), beam_width)
+        first = idx[0, 0].item()
+        beam = [(ix[0, i], lp[0, i], [first, ix[0, i].item()]) for i in range(beam_width)]
+        for _ in range(max_new_tokens - 1):
+            cands = []
+            for last, score, toks in beam:
+                idx = torch.cat((idx, last.reshape(1, 1)), dim=-1)
+                _, logits = self(idx, prefix=prefix)
+                lp, ix = torch.topk(torch.log_softmax(logits[:, -1, :].float(), dim=-1), beam_width)
+                for i in range(beam_width):
+                    cands.append((ix[0, i], score + lp[0, i], toks + [ix[0, i].item()]))
+            beam = sorted(cands, key=lambda c: float(c[1]), reverse=True)[:beam_width]
+        self.last_beam_scores = [float(b[1]) for b in beam]
+        return beam[0][2]

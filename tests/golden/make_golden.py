@@ -230,7 +230,11 @@ def main():
                 _, lg = g(cur, prefix=prefix[:1].detach())
                 steps.append(lg[0, -1].detach().numpy())
                 cur = torch.cat([cur, lg[:, -1].argmax(-1, keepdim=True)], 1)
-            save("gpt_generate", start=start.numpy(), tokens=gen.numpy(), step_logits=np.stack(steps), tokens_argmax=cur[0].numpy())
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                bs = g.beam_search(start.clone(), 5, prefix[:1].detach(), beam_width=3)
+            save("gpt_generate", start=start.numpy(), tokens=gen.numpy(), step_logits=np.stack(steps), tokens_argmax=cur[0].numpy(),
+                 beam_tokens=np.array(bs, dtype=np.int64))
 
     # ---- cfg1: Franky(BrainEncoder + gpt2-nano), B=4, T=200, + 2 optimizer steps
     enc = bf.MAEConfig(window_size=200, n_electrodes=256, patch_size=25, dim=128, n_layers=2, head_dim=32,

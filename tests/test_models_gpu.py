@@ -180,6 +180,19 @@ def test_gpt_generate_graph_matches_reference(golden):
     assert torch.equal(ca[0][:, :pos + 1], cb[0][:, :pos + 1])
 
 
+def test_gpt_beam_search_matches_reference(golden):
+    """GPT.beam_search (models/gpt2_model.py:419-454, deterministic, shared-context quirk included) vs the reference's tokens;
+    generate_beam_search (:355-416, stochastic) returns a well-formed sequence."""
+    z = golden("gpt_generate")
+    cfgo, prefix, tk, idx = C.gpt_small(True)
+    g = load_synth(mk_gpt(cfgo)).eval()
+    start = torch.from_numpy(z["start"]).cuda()
+    pf = prefix[:1].cuda()
+    assert g.beam_search(start.clone(), 5, pf, beam_width=3) == z["beam_tokens"].tolist()
+    out = g.generate_beam_search(start.clone(), 6, pf, topk=10, beam_width=4)
+    assert out.shape == (4 + 6,) and torch.equal(out[:4].cpu(), start[0].cpu()) and int(out.max()) < cfgo.vocab_size
+
+
 def build_franky():
     from frankenstein_amd.models.notebook_models import BrainEncoder, Franky
     bcfg, gcfg, x, tok = C.cfg1()
