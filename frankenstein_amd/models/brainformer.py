@@ -438,6 +438,16 @@ class MAE(nn.Module):
         return (loss, None)
 
 
+def _mae_get_sub_att_matrix(self, attn_mask, unmasked_indices):
+    """Dense form of the gathered block-causal sub-mask, [b, 1, n, n] bool (models/brainformer.py:392-413).  Kept for API parity and
+    for checking: the forward itself passes the same mask analytically (kernels.Mask.from_token_ids), never as a tensor."""
+    sub = attn_mask[unmasked_indices[:, :, None], unmasked_indices[:, None, :]]
+    return sub[:, None]
+
+
+MAE.get_sub_att_matrix = _mae_get_sub_att_matrix
+
+
 class BrainFormer(nn.Module):
     config = Config
     head_name = 'to_motion'
@@ -497,3 +507,21 @@ class BrainFormer(nn.Module):
         x = torch.from_numpy(myo)[None].to(self.device).float()
         pred = self.forward(x, targets=None)[1]
         return pred[0].float().cpu().numpy().T
+
+
+
+def default_generation(model, emg, stride=8):
+    """Sliding-window latency loop of the reference (models/brainformer.py:579-597): emg [Time, n_channels]."""
+    ws = model.config.window_size
+    sample = emg[:ws]
+    for i in range(int((emg.size(0) - ws) // stride)):
+        model(sample[None, ...])
+        sample = emg[i * stride:i * stride + ws]
+    return 'Completed'
+
+
+@torch.no_grad()
+def cache_generation(model, emg, stride=8):
+    """The reference's variant (:599-618) passes use_kv_cache=True to a forward that has no such argument (stale code); the same
+    windows are run through the plain forward here."""
+    return default_generation(model, emg, stride)

@@ -16,8 +16,9 @@ import torch.nn as nn
 from .. import engine as E
 from .. import kernels as K
 from ..kernels import Mask
-from .brainformer import (MLP, CausalSelfAttention, LayerNorm, Linear, RMSNorm, Serializable, _prep,
-                          build_complex_rope_cache)
+from .brainformer import (MLP, CausalCrossAttention, CausalSelfAttention, CrossBlock, LayerNorm, Linear, RMSNorm,  # noqa: F401
+                          Serializable, _prep, apply_rope, build_advanced_causal_mask, build_complex_rope_cache)
+# (the reference file carries private copies of these building blocks, models/simple_mae:1-227; here they are the shared ones)
 
 
 @dataclass

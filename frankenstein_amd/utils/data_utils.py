@@ -19,6 +19,11 @@ from .._lib import call, lib
 MAX_INPUT_LEN = 768
 MAX_TOKENS = 25
 
+# recording sessions of the T12 data set in chronological order (the reference's DATE_TO_INDEX, utils/data_utils.py:14-38)
+_DATES = ["04.28", "05.05", "05.17", "05.19", "05.24", "05.26", "06.02", "06.07", "06.14", "06.16", "06.21", "06.23", "06.28",
+          "07.05", "07.14", "07.21", "07.27", "07.29", "08.02", "08.11", "08.13", "08.18", "08.23", "08.25"]
+DATE_TO_INDEX = {f"t12.2022.{d}": i for i, d in enumerate(_DATES)}
+
 
 def _pack(brain_list: Sequence[np.ndarray], block_list, device):
     lens = [int(b.shape[0]) for b in brain_list]
@@ -93,3 +98,103 @@ def pad_token_list(token_list, max_tokens):
 
 def remove_padding(token_list):
     return [t for t in token_list if t != -100]
+
+
+# ------------------------------------------------------------------------------------------------ host-side glue
+# File parsing, text clean-up and the dataset wrapper are host code in the reference too (utils/data_utils.py:40-76,159-228,230-241,
+# 270-281,291-344); only their signal processing runs on the device (above).
+def min_max_per_block_scaling(brain_list, idx_list):
+    """Per-block MinMaxScaler (:44-75): (x - min) / (max - min) with the block's per-channel extrema (constant channels -> 0)."""
+    blocks = {}
+    for i, b in enumerate(idx_list):
+        blocks.setdefault(b, []).append(i)
+    out = [None] * len(brain_list)
+    for members in blocks.values():
+        cat = np.concatenate([brain_list[i] for i in members])
+        lo, span = cat.min(axis=0), cat.max(axis=0) - cat.min(axis=0)
+        span = np.where(span == 0, 1.0, span)
+        for i in members:
+            out[i] = (brain_list[i] - lo) / span
+    return out
+
+
+def process_text(arr):
+    return [t.strip() for t in arr]
+
+
+def process_file(data_file):
+    """One session .mat file -> (z-scored spike-power trials, sentences, dates) like :162-187 (z-score on the device)."""
+    import scipy.io
+    data = scipy.io.loadmat(data_file)
+    n_trials = data["blockIdx"].shape[0]
+    voltage_list = data["spikePow"][0][:]
+    block_list = data["blockIdx"][:, 0]
+    brain_list = z_score_per_block_scaling(list(voltage_list), list(block_list))
+    return brain_list, process_text(data["sentenceText"]), [data_file.stem] * n_trials
+
+
+def process_all_files(path):
+    data = {"brain_list": [], "sentence_list": [], "date_list": []}
+    for f in sorted(path.glob("*.mat")):
+        brains, sentences, dates = process_file(f)
+        data["brain_list"].extend(brains)
+        data["sentence_list"].extend(sentences)
+        data["date_list"].extend(dates)
+    return data
+
+
+def remove_punctuation(text):
+    import string
+    drop = set(string.punctuation) - {"'"}
+    return "".join(ch for ch in text if ch not in drop)
+
+
+def process_string(text):
+    return remove_punctuation(text.lower())
+
+
+def save_sentences_to_txt(fpath, sentences, string_processing_fn):
+    with open(fpath, "w", encoding="utf-8") as f:
+        f.writelines(string_processing_fn(s_) + "\n" for s_ in sentences)
+
+
+def load_sentences_from_txt(fpath):
+    with open(fpath, "r", encoding="utf-8") as f:
+        return [line.strip() for line in f]
+
+
+def find_long_samples(sample_list, max_length):
+    return [i for i, s_ in enumerate(sample_list) if len(s_) > max_length]
+
+
+def get_tokenizer(tokenizer):
+    bos, eos = tokenizer.bos_token, tokenizer.eos_token
+
+    def tokenize_txt(text):
+        return tokenizer(bos + text + eos).input_ids
+    return tokenize_txt
+
+
+class BrainDataset(torch.utils.data.Dataset):
+    """(input [768, C] float32, padded token targets, date) per trial, as the reference's dataset (:291-344)."""
+
+    def __init__(self, path, tokenize_function=None):
+        print("Runed processing of the ", path)
+        data = process_all_files(path)
+        self.inputs, self.targets, self.date = data["brain_list"], data["sentence_list"], data["date_list"]
+        self.date_to_index = DATE_TO_INDEX
+        if tokenize_function is not None:
+            self.targets_tokens = [np.asarray(pad_token_list(tokenize_function(t), MAX_TOKENS), dtype=np.int64) for t in self.targets]
+        else:
+            self.targets_tokens = self.targets[:]
+        self.inputs = pad_truncate_brain_list(self.inputs, MAX_INPUT_LEN)
+
+    def __len__(self) -> int:
+        return len(self.inputs)
+
+    def remove_bad_samples(self, bad_indices):
+        for i in reversed(bad_indices):
+            del self.inputs[i], self.targets[i], self.targets_tokens[i], self.date[i]
+
+    def __getitem__(self, idx: int):
+        return self.inputs[idx].astype(np.float32), self.targets_tokens[idx], self.date[idx]
