@@ -190,7 +190,7 @@ def main():
                 traffic = pm["fk_attn_bwd_bytes_per_call"] if bwd else None
             except Exception:
                 pass
-            roof = {"kernel": "fk_attn_bwd (attn_bwd_dkdv + attn_bwd_dq + attn_delta launches of one call)" if bwd else "fk_attn_fwd",
+            roof = {"kernel": "fk_attn_bwd (attn_bwd_dq [+ delta] and attn_bwd_dkdv launches of one call)" if bwd else "fk_attn_fwd",
                     "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(fl / avg_s / MFMA_PEAK_BF16, 4), "traffic": traffic,
                     "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r01_pmc_traffic.json); algorithmic bytes 1.21e9",

@@ -16,7 +16,7 @@
 //   dkdv: one workgroup per 128 keys, wave = 32 keys ("key on the lane"): S = Q K^T, dP = dO V^T,
 //         dV^T += dO^T P, dK^T += Q^T dS, sweeping the visible query tiles;
 //   dq  : forward-shaped: S^T, dP^T = V dO^T, dQ^T += K^T dS^T.
-// P is recomputed from the saved log-sum-exp; delta = rowsum(dO * O) comes from a small pre-pass.
+// P is recomputed from the saved log-sum-exp; delta = rowsum(dO * O) is computed by the dQ kernel (which runs first) and read by dK/dV.
 // fp32 variants (exact-fp32 MFMA) exist for the parity mode.
 #include "fk_common.h"
 
@@ -441,32 +441,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
     p.LSE[((int64_t)b * p.H + hd) * p.Nq + qrow] = lt > 0.0f ? m * p.scale + logf(lt) : INFINITY;
 }
 
-// ================================================================================================= delta
-template <typename T, int D>
-__global__ void attn_delta_kernel(AttnArgs p) {
-  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)p.B * p.H * p.Nq;
-  if (idx >= total) return;
-  const int q = (int)(idx % p.Nq), hd = (int)((idx / p.Nq) % p.H), b = (int)(idx / ((int64_t)p.Nq * p.H));
-  const T* o = (const T*)p.O + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + hd * D;
-  const T* g = (const T*)p.dO + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + hd * D;
-  float s = 0.0f;
-  constexpr int VEC = 16 / sizeof(T);
-#pragma unroll
-  for (int i = 0; i < D / VEC; ++i) {
-    if constexpr (sizeof(T) == 2) {
-      bf16x8 a = *reinterpret_cast<const bf16x8*>(o + i * 8), c = *reinterpret_cast<const bf16x8*>(g + i * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
-    } else {
-      f32x4 a = *reinterpret_cast<const f32x4*>(o + i * 4), c = *reinterpret_cast<const f32x4*>(g + i * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s += a[e] * c[e];
-    }
-  }
-  p.delta[idx] = s;   // [B, H, Nq]
-}
-
 // ================================================================================================= dQ
 template <typename T, int D>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
@@ -507,7 +481,24 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   }
   const int64_t stat = ((int64_t)b * p.H + hd) * p.Nq + qrow;
   const float lse2 = q_ok ? p.LSE[stat] * LOG2E : INFINITY;   // +inf -> P = 0 for padded rows
-  const float dl = q_ok ? p.delta[stat] : 0.0f;
+  // delta = rowsum(dO * O): this kernel already holds the dO row fragments, so it computes delta itself (one extra read of O) and
+  // publishes it for the dK/dV kernel, which is launched after this one; no separate delta launch
+  float dl = 0.0f;
+  {
+    const T* Op = (const T*)p.O + (int64_t)b * p.o_bs + hd * D;
+    float part = 0.0f;
+#pragma unroll
+    for (int s = 0; s < C::KSTEPS; ++s) {
+      if (q_ok && 16 * s + 8 * lh < D) {
+        Frag<T> of;
+        frag_load_contig<T>(of, Op + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += to_f32<T>(of.v[e]) * to_f32<T>(gf[s].v[e]);
+      }
+    }
+    dl = part + __shfl_xor(part, 32, 64);
+    if (q_ok && lh == 0) p.delta[stat] = dl;
+  }
 
   const int q_last = min(q0 + BQ, p.Nq) - 1;
   const int kv_end = p.mask_kind == FK_MASK_KEYPAD ? p.Nk : kv_limit(p, b, q_last);
@@ -835,15 +826,14 @@ template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
   return 0;
 }
 template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
-  const int64_t total = (int64_t)a.B * a.H * a.Nq;
-  hipLaunchKernelGGL((attn_delta_kernel<T, D>), dim3((unsigned)fk_cdiv(total, 256)), dim3(256), 0, s, a);
+  // dQ first: it also writes delta = rowsum(dO * O) [B, H, Nq], which the dK/dV kernel reads
   dim3 gk((unsigned)(((a.Nk + 127) / 128) * a.H * a.B));
   const size_t lds_kv = dkdv_lds<T, D>(), lds_q = dq_lds<T, D>();
   allow_lds(attn_bwd_dkdv_kernel<T, D>, lds_kv);
   allow_lds(attn_bwd_dq_kernel<T, D>, lds_q);
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D>), gk, dim3(NT), lds_kv, s, a);
   dim3 gq((unsigned)(((a.Nq + BQ - 1) / BQ) * a.H * a.B));
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), gq, dim3(NT), lds_q, s, a);
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D>), gk, dim3(NT), lds_kv, s, a);
   return 0;
 }
 
