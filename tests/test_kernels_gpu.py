@@ -550,3 +550,22 @@ def test_full_size_kernels_are_deterministic():
         runpy.run_path(os.path.join(os.path.dirname(__file__), "..", "tools", "determinism_probe.py"), run_name="__main__")
     out = buf.getvalue()
     assert "DETERMINISTIC" in out and "DIFFERS" not in out and "MISMATCH" not in out and out.count(" OK ") >= 13, out
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_degenerate_shapes(K, dtype):
+    """Smallest legal problems: one row / one key / one column vector — nothing may read or write out of bounds."""
+    a, w = rnd(1, 8, seed=1), rnd(8, 8, seed=2)
+    close(K.gemm_nt(dev(a, dtype), dev(w, dtype)), q(a, dtype) @ q(w, dtype).t(), dtype, atol32=1e-5)
+    close(K.gemm_tn(dev(a, dtype), dev(a, dtype)), q(a, dtype).t() @ q(a, dtype), torch.float32, atol32=1e-5)
+    x = rnd(1, 8, seed=3)
+    y, mean, rstd = K.norm_fwd(dev(x, dtype), torch.ones(8, device="cuda"), torch.zeros(8, device="cuda"), 1e-5)
+    close(y, torch.nn.functional.layer_norm(q(x, dtype), (8,)), dtype, atol32=1e-5)
+    close(K.colsum(dev(x, dtype)), q(x, dtype)[0], torch.float32, atol32=1e-6)
+    qq = rnd(1, 1, 16, seed=4).view(1, 1, 1, 16)
+    o, lse = K.attn_fwd(dev(qq, dtype), dev(qq, dtype), dev(qq, dtype), K.Mask(K.MASK_CAUSAL))
+    close(o, q(qq, dtype), dtype, atol32=1e-6)                          # a single key: softmax weight 1
+    dq, dk, dv = (torch.empty_like(o) for _ in range(3))
+    K.attn_bwd(dev(qq, dtype), dev(qq, dtype), dev(qq, dtype), o, torch.ones_like(o), lse, dq, dk, dv, K.Mask(K.MASK_CAUSAL))
+    close(dv, torch.ones_like(qq), dtype, atol32=1e-6)
+    assert float(dq.abs().max()) < 1e-5 and float(dk.abs().max()) < 1e-5     # softmax over one key is constant
