@@ -175,10 +175,13 @@ __global__ void cast_pack_kernel(const float* src, int64_t lds, T* dst, int64_t 
     else dst[(int64_t)rd * ldd + c] = from_f32<T>(v);
   }
 }
-// all shadow re-packs of a step in one launch: a block takes 1024-element chunks, finds the owning job by a (block-uniform)
-// binary search over chunk_begin and then does what cast_pack_kernel does
+// all shadow re-packs of a step in one launch: a block takes chunks, finds the owning job by a (block-uniform) binary search over
+// chunk_begin and then does what cast_pack_kernel does.  Plain jobs: a chunk = 1024 consecutive elements.  Transposed jobs: a chunk =
+// one 32 x 32 source tile, read row-wise and written column-wise through LDS, so both sides move 128-byte segments (the element-wise
+// form fetched 16x the bytes it needed).
 template <typename T>
-__global__ void cast_pack_multi_kernel(const fk_pack_job* jobs, int njobs, int64_t total_chunks) {
+__global__ __launch_bounds__(256) void cast_pack_multi_kernel(const fk_pack_job* jobs, int njobs, int64_t total_chunks) {
+  __shared__ float tile[32][33];
   for (int64_t ch = blockIdx.x; ch < total_chunks; ch += gridDim.x) {
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
@@ -186,19 +189,37 @@ __global__ void cast_pack_multi_kernel(const fk_pack_job* jobs, int njobs, int64
       if (jobs[mid].chunk_begin <= ch) lo = mid; else hi = mid - 1;
     }
     const fk_pack_job jb = jobs[lo];
-    const int64_t total = (int64_t)jb.rows * jb.cols, base = (ch - jb.chunk_begin) * 1024;
     T* dst = (T*)jb.dst;
+    const int64_t local = ch - jb.chunk_begin;
+    if (!jb.transpose) {
+      const int64_t total = (int64_t)jb.rows * jb.cols, base = local * 1024;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int64_t i = base + q * 256 + threadIdx.x;
-      if (i >= total) break;
-      int r, c;
-      if (jb.transpose) { r = (int)(i % jb.rows); c = (int)(i / jb.rows); }
-      else { r = (int)(i / jb.cols); c = (int)(i % jb.cols); }
-      const int rd = jb.rblk > 0 ? (r / jb.rblk) * jb.rstride + (r % jb.rblk) + jb.roff : r;
-      const float v = jb.src[(int64_t)r * jb.lds + c];
-      if (jb.transpose) dst[(int64_t)c * jb.ldd + rd] = from_f32<T>(v);
-      else dst[(int64_t)rd * jb.ldd + c] = from_f32<T>(v);
+      for (int q = 0; q < 4; ++q) {
+        const int64_t i = base + q * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int r = (int)(i / jb.cols), c = (int)(i % jb.cols);
+        const int rd = jb.rblk > 0 ? (r / jb.rblk) * jb.rstride + (r % jb.rblk) + jb.roff : r;
+        dst[(int64_t)rd * jb.ldd + c] = from_f32<T>(jb.src[(int64_t)r * jb.lds + c]);
+      }
+    } else {
+      const int tcols = (jb.cols + 31) / 32;
+      const int r0 = (int)(local / tcols) * 32, c0 = (int)(local % tcols) * 32;
+      const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+      __syncthreads();                                     // previous chunk's tile fully consumed
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + ty + 8 * q, c = c0 + tx;
+        tile[ty + 8 * q][tx] = (r < jb.rows && c < jb.cols) ? jb.src[(int64_t)r * jb.lds + c] : 0.0f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + ty + 8 * q, r = r0 + tx;
+        if (r < jb.rows && c < jb.cols) {
+          const int rd = jb.rblk > 0 ? (r / jb.rblk) * jb.rstride + (r % jb.rblk) + jb.roff : r;
+          dst[(int64_t)c * jb.ldd + rd] = from_f32<T>(tile[tx][ty + 8 * q]);
+        }
+      }
     }
   }
 }

@@ -255,7 +255,7 @@ def refresh_shadows(params: Sequence[Tensor]) -> None:
             for src, dst, tr, rblk, rstride, roff in e.jobs:
                 r, c = src.shape
                 rows.append((src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0), r, c, int(tr), rblk, rstride, roff, chunks))
-                chunks += (r * c + 1023) // 1024
+                chunks += ((r + 31) // 32) * ((c + 31) // 32) if tr else (r * c + 1023) // 1024
         tab = torch.from_numpy(np.array(rows, dtype=rec).view(np.uint8).copy()).to(ents[0].tensor.device)
         _REFRESH.update(sig=sig, table=tab, njobs=len(rows), chunks=chunks, ents=ents)
     K.cast_pack_multi(_REFRESH["table"], _REFRESH["njobs"], _REFRESH["chunks"], _COMPUTE_DTYPE)

@@ -129,8 +129,9 @@ int fk_cast_pack(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t 
 int fk_cast_pack_rows(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int transpose,
                       int64_t rblk, int64_t rstride, int64_t roff, int dtype, void* stream);
 /* many fk_cast_pack_rows jobs in ONE launch: the per-step refresh of every weight shadow after the optimizer update
- * (replaces ~150 tiny launches).  `jobs` is a DEVICE array; job j owns the 1024-element chunks
- * [chunk_begin, next job's chunk_begin) of its rows*cols elements; total_chunks = end of the last job.                */
+ * (replaces ~150 tiny launches).  `jobs` is a DEVICE array; job j owns the chunks [chunk_begin, next job's chunk_begin):
+ * ceil(rows*cols / 1024) chunks of 1024 consecutive elements for a plain job, ceil(rows/32) * ceil(cols/32) tiles of 32 x 32 source
+ * elements for a transposed one; total_chunks = end of the last job.                                                  */
 typedef struct fk_pack_job {
   const float* src; void* dst; int64_t lds, ldd;
   int32_t rows, cols, transpose, rblk, rstride, roff;
