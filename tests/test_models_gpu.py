@@ -548,3 +548,37 @@ def test_bf16_odd_shapes_train_steps():
         assert firsts[0][0] == firsts[1][0] and torch.equal(firsts[0][1], firsts[1][1])
     finally:
         fa.set_compute_dtype("fp32")
+
+
+def test_simple_mae_baseline_size_bf16():
+    """BASELINE configs[4] at the size SURVEY 8d names (6-layer d=384 encoder on 600 frame tokens, 2-layer decoder, 75 % masking),
+    bf16, B = 16 with zero-padded tails: finite decreasing loss over a few optimiser steps, run-to-run identical first step."""
+    from frankenstein_amd.models import simple_mae as sm
+    from frankenstein_amd.utils import train_utils as tu
+    fa.set_compute_dtype("bf16")
+    try:
+        ecfg = sm.SimpleEncoderConfig(block_size=600, patch_size=256, n_layers=6, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+        dcfg = sm.SimpleMAEConfig(n_layers=2, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        x = torch.randn(16, 600, 256, device="cuda", generator=g)
+        for b in range(16):
+            x[b, 600 - 7 * b:] = 0.0                              # padded tails of different lengths
+        keep = torch.stack([torch.randperm(600, device="cuda", generator=g) for _ in range(16)])
+        idx = (keep[:, 150:].sort(1).values.contiguous(), keep[:, :150].sort(1).values.contiguous())   # (masked, unmasked)
+        first = []
+        for rep in range(2):
+            torch.manual_seed(0)
+            m = sm.SimpleMAE(ecfg, dcfg).cuda()
+            opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=0.0, grad_clip=1.0)
+            losses = []
+            for step in range(5):
+                out = m(x, indices=idx)
+                loss = out[0] if isinstance(out, tuple) else out
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+            assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+            first.append(losses[0])
+        assert first[0] == first[1]
+    finally:
+        fa.set_compute_dtype("fp32")
