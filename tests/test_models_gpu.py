@@ -582,3 +582,30 @@ def test_simple_mae_baseline_size_bf16():
         assert first[0] == first[1]
     finally:
         fa.set_compute_dtype("fp32")
+
+
+def test_vq_plus_brainformer_pipeline_bf16():
+    """BASELINE configs[3]: SoundStream(C=256, D=64, codebook 1024, 256 electrodes) tokenizes [B, 600, 256] into
+    quantised codes [B, 150, 64]; a brainformer with window 150 / 64 'electrodes' / patch 25 trains on them (the reference only
+    describes this wiring in its README).  Finite, decreasing loss."""
+    from frankenstein_amd.models import brainformer as bf, vq_brain as vq
+    from frankenstein_amd.utils import train_utils as tu
+    fa.set_compute_dtype("bf16")
+    try:
+        torch.manual_seed(0)
+        tok = vq.SoundStream(C=256, D=64, codebook_size=1024, n_electrodes=256).cuda().eval()
+        enc = bf.MAEConfig(window_size=150, n_electrodes=64, patch_size=25, dim=384, n_layers=2, head_dim=64, hidden_dim=1536, n_heads=6, n_kv_heads=6)
+        cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=384, n_layers=2, head_dim=64, hidden_dim=768, n_heads=6, n_kv_heads=6)
+        m = bf.BrainFormer(cfg).cuda()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(8, 600, 256, device="cuda", generator=g)
+        y = torch.randn(8, 32, 128, device="cuda", generator=g)
+        with torch.no_grad():
+            idx, codes = tok.get_quantize_vectors(x)
+        assert tuple(codes.shape) == (8, 150, 64) and int(idx.max()) < 1024
+        opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=0.0, grad_clip=1.0)
+        tc = tu.TrainConfig(mixed_precision=True, use_scheduler=False, learning_rate=1e-3)
+        losses = [float(tu.train_step(m, (codes.float(), y, None), opt, s, tc)) for s in range(5)]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    finally:
+        fa.set_compute_dtype("fp32")
