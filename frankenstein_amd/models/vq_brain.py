@@ -206,13 +206,12 @@ class VectorQuantize(nn.Module):
         n = cb.cluster_size[0].sum()
         smoothed = (cb.cluster_size[0] + self.eps) / (n + Kc * self.eps) * n
         cb.embed[0].copy_(torch.nn.functional.normalize(cb.embed_avg[0] / smoothed[:, None], dim=-1))
+        # dead-code re-seeding without a host round trip (no data-dependent shapes: capturable in a hipGraph)
         dead = cb.cluster_size[0] < self.dead
-        nd = int(dead.sum())
-        if nd:
-            pick = torch.randint(0, xn.shape[0], (nd,), device=xn.device)
-            cb.embed[0][dead] = xn[pick]
-            cb.embed_avg[0][dead] = xn[pick] * self.dead
-            cb.cluster_size[0][dead] = float(self.dead)
+        seed = xn[torch.randint(0, xn.shape[0], (Kc,), device=xn.device)]
+        cb.embed[0].copy_(torch.where(dead[:, None], seed, cb.embed[0]))
+        cb.embed_avg[0].copy_(torch.where(dead[:, None], seed * self.dead, cb.embed_avg[0]))
+        cb.cluster_size[0].masked_fill_(dead, float(self.dead))
 
 
 class SoundStream(nn.Module):
@@ -243,6 +242,8 @@ class SoundStream(nn.Module):
         return indices, quantized
 
     def calculate_perp(self, indices):
-        counts = torch.bincount(indices.reshape(-1), minlength=self.codebook_size).float()
+        flat = indices.reshape(-1)
+        counts = torch.zeros(self.codebook_size, dtype=torch.float32, device=flat.device)
+        counts.index_add_(0, flat, torch.ones_like(flat, dtype=torch.float32))     # bincount() would sync for its size
         p = counts / counts.sum()
         return (-(p * torch.log(p + 1e-10)).sum()).exp()

@@ -266,6 +266,58 @@ def train_step(model, batch, optimizer: FusedAdamW, step: int, cfg: TrainConfig,
     return loss.detach()
 
 
+class GraphedTrainStep:
+    """The hot loop's forward + backward captured ONCE as a hipGraph and replayed per batch; the update (whose learning
+    rate changes every step) runs eagerly after each replay.  For the small configurations (gpt2-nano, SimpleMAE B=32)
+    a step is ~300 launches of a few microseconds each and the Python/ctypes launch path, not the GPU, sets the step
+    time; replaying a graph removes it.  Requirements: static batch shape, one process (the gradient exchange is
+    hook-driven and not captured), grad_accum == 1, a forward without host-side randomness, no weight-gradient side
+    stream.  Same numbers as ``train_step``: the captured kernels are the ones the eager step launches."""
+
+    def __init__(self, model, batch, optimizer: FusedAdamW, cfg: TrainConfig, scheduler=None, warmup: int = 2):
+        if _dist_info()[1] != 1:
+            raise RuntimeError("GraphedTrainStep is single-process: the bucketed gradient exchange is not captured")
+        if cfg.grad_accum != 1:
+            raise RuntimeError("GraphedTrainStep needs grad_accum == 1")
+        if E.wgrad_stream() is not None:
+            raise RuntimeError("GraphedTrainStep needs the weight-gradient side stream off")
+        self.model, self.optimizer, self.cfg = model, optimizer, cfg
+        self.get_lr = scheduler or init_lr_scheduler(cfg)
+        self.static = tuple(t.clone() if torch.is_tensor(t) else t for t in batch)
+        optimizer.sync.enabled = False
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                  # warm-up off the default stream: workspaces, shadows, autotune
+            for _ in range(warmup):
+                self._fwd_bwd()
+        cur.wait_stream(side)
+        optimizer.zero_grad()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._fwd_bwd()
+        optimizer.zero_grad()                          # capture recorded the launches, it did not run them
+
+    def _fwd_bwd(self):
+        inputs, labels, date_info = self.static
+        loss, _ = self.model(inputs, labels, date_info=date_info)
+        loss.backward()
+        return loss.detach()
+
+    def __call__(self, batch, step: int):
+        for dst, src in zip(self.static, batch):
+            if torch.is_tensor(dst):
+                if dst.shape != src.shape:
+                    raise RuntimeError(f"GraphedTrainStep was captured for {tuple(dst.shape)}, got {tuple(src.shape)}")
+                dst.copy_(src, non_blocking=True)
+        lr = self.get_lr(step)
+        for g in self.optimizer.param_groups:
+            g['lr'] = lr
+        self.graph.replay()
+        self.optimizer.step()
+        return self.loss
+
+
 def _dist_info():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

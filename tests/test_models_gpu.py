@@ -609,3 +609,40 @@ def test_vq_plus_brainformer_pipeline_bf16():
         assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     finally:
         fa.set_compute_dtype("fp32")
+
+
+def test_graphed_train_step_is_bit_identical_to_eager():
+    """train_utils.GraphedTrainStep (forward + backward replayed from one hipGraph, update eager) against train_step on
+    the same seeded batches with a cosine schedule: same losses and same parameters bit for bit after 5 steps; a batch of
+    another shape is refused."""
+    from frankenstein_amd.models import brainformer as bf
+    from frankenstein_amd.utils import train_utils as tu
+    fa.set_compute_dtype("bf16")
+    try:
+        enc = bf.MAEConfig(window_size=200, n_electrodes=64, patch_size=25, dim=128, n_layers=2, head_dim=32, hidden_dim=512,
+                           n_heads=4, n_kv_heads=4)
+        cfg = bf.Config(encoder=enc, n_output_tokens=8, output_dim=20, dim=128, n_layers=1, head_dim=32, hidden_dim=256,
+                        n_heads=4, n_kv_heads=4)
+        g = torch.Generator(device="cuda").manual_seed(11)
+        batches = [(torch.randn(4, 200, 64, device="cuda", generator=g), torch.randn(4, 8, 20, device="cuda", generator=g), None)
+                   for _ in range(5)]
+        tc = tu.TrainConfig(mixed_precision=True, use_scheduler=True, learning_rate=1e-3, warmup_iters=2, max_steps=10,
+                            lr_decay_iters=10)
+        runs = []
+        for graphed in (False, True):
+            torch.manual_seed(0)
+            m = bf.BrainFormer(cfg).cuda()
+            opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=1e-2, grad_clip=1.0)
+            if graphed:
+                step = tu.GraphedTrainStep(m, batches[0], opt, tc)
+                losses = [float(step(b, i)) for i, b in enumerate(batches)]
+                with pytest.raises(RuntimeError, match="captured for"):
+                    step((batches[0][0][:2], batches[0][1][:2], None), 5)
+            else:
+                losses = [float(tu.train_step(m, b, opt, i, tc)) for i, b in enumerate(batches)]
+            assert opt.t == 5
+            runs.append((losses, opt.arena.flat.detach().clone(), opt.m.clone()))
+        assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+        assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    finally:
+        fa.set_compute_dtype("fp32")

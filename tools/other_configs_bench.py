@@ -52,3 +52,17 @@ def step3():
     tu.train_step(fr, (x, tok, None), opt3, st[0], tc); st[0] += 1
 dt = timeit(step3)
 print(f"cfg1 Franky (gpt2-nano decoder) B=   4: {dt * 1e3:7.2f} ms/step  {4 * 200 / dt / 1e3:9.1f} k frames/s")
+
+# the same steps with forward + backward replayed from one hipGraph (train_utils.GraphedTrainStep)
+def graphed(name, model, batch, opt, units):
+    try:
+        g = tu.GraphedTrainStep(model, batch, opt, tc)
+        dt = timeit(lambda: g(batch, 0))
+        print(f"{name:32s} graphed: {dt * 1e3:7.2f} ms/step  {units / dt / 1e3:9.1f} k frames/s")
+    except Exception as e:       # a forward with a host sync cannot be captured
+        print(f"{name:32s} graphed: not capturable ({type(e).__name__}: {str(e)[:120]})")
+        torch.cuda.synchronize()
+
+graphed("cfg1 Franky (gpt2-nano decoder)", fr, (x, tok, None), opt3, 4 * 200)
+graphed("cfg4 SoundStream tokenizer", net, (torch.randn(16, 768, 512, device="cuda"), None, None), opt2, 16 * 768)
+graphed("cfg5 SimpleMAE B=32", m, (torch.randn(32, 600, 256, device="cuda"), None, None), opt, 32 * 600)
