@@ -496,6 +496,154 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
   }
 }
 
+// Ring-buffered NT kernels for the wide bf16 projections.  The double-buffered kernels above keep ONE k-stage in flight per block
+// and drain it (vmcnt(0)) at every barrier: measured with the MFMAs compiled out (tools/gemm_ksweep.py on a probe build) the fetch
+// stream alone takes 83 % of the per-k time, and one stage in flight fetches 1.35x slower than two -- the loop is bound by
+// memory latency x bytes in flight, not by MFMA or LDS rate.  Here the k-stages of ALL tiles of a persistent block form one stream
+// through NS ring slots: stage g+NS-1 is issued when stage g starts computing, the wait before stage g is the counted
+// `s_waitcnt vmcnt((NS-2) PER)` (vmcnt retires in order; PER = LDS-DMA instructions per wave and stage), and the stream runs across
+// tile boundaries, so the next tile's first stages land during the epilogue.  The epilogue stages through the slot just computed
+// plus the LDS above the ring.  Two shapes, both 8 waves and the whole 160 KiB of a CU:
+//   N % 256 == 0 : 256 x 256 tile, 32-element k-stages (64-B image rows), NS = 4  (3 x 32 KiB in flight)
+//   N % 128 == 0 : 256 x 128 tile, 64-element k-stages (128-B image rows), NS = 3 (2 x 48 KiB in flight)
+template <int N> FK_DEV void vm_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+template <int BN_, int RB, int NS> struct Ring {
+  static constexpr int BM_ = 256;
+  static constexpr int STAGE = (BM_ + BN_) * RB, A_BYTES = BM_ * RB;
+  static constexpr int IN_SLOT = STAGE / 8192 < 8 ? STAGE / 8192 : 8;       // waves whose 8-KiB epilogue slice fits in a ring slot
+  static constexpr int LDS = NS * STAGE + (8 - IN_SLOT) * 8192;
+  static constexpr int APW = BM_ * RB / 8192, BPW = BN_ * RB / 8192, PER = APW + BPW;
+  static_assert(LDS <= 160 * 1024, "ring does not fit the LDS of a CU");
+};
+// image of a k-stage: row r holds RB bytes; its 16-byte chunk c sits at chunk c ^ swz(r) (conflict-free ds_read_b128 down a column)
+template <int RB> FK_DEV int ring_swz(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int RB> FK_DEV int ring_off(int row, int chunk) { return row * RB + ((chunk ^ ring_swz<RB>(row)) << 4); }
+
+template <typename TO, int BN_, int RB, int NS>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
+  using T = bf16_t;
+  using R = Ring<BN_, RB, NS>;
+  constexpr int BM_ = R::BM_, STAGE = R::STAGE, A_BYTES = R::A_BYTES, APW = R::APW, BPW = R::BPW, PER = R::PER;
+  constexpr int BKE = RB / 2, SSTEPS = RB / 32, RPI = 1024 / RB, LPR = RB / 16;   // k elements / k16 steps per stage; rows, lanes per row of a DMA
+  constexpr int WCOLS = BN_ / 64, WROWS = 8 / WCOLS, WM = BM_ / WROWS, MT = WM / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WCOLS, wn = wave % WCOLS, li = lane & 31, lh = lane >> 5;
+  const int ntn = (p.N + BN_ - 1) / BN_;
+  const int ntiles = ((p.M + BM_ - 1) / BM_) * ntn;
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = (nb + 7 - xcd) >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int t_beg = xcd * q8 + min(xcd, r8), t_end = t_beg + q8 + (xcd < r8 ? 1 : 0);
+  const int nk = p.K / BKE;
+
+  const T* srcA[APW];
+  const T* srcB[BPW];
+  auto set_src = [&](int tile) {
+    const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const int row = (wave * APW + j) * RPI + lane / LPR;
+      srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ((lane % LPR) ^ ring_swz<RB>(row)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      const int row = (wave * BPW + j) * RPI + lane / LPR;
+      srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ((lane % LPR) ^ ring_swz<RB>(row)) * 8;
+    }
+  };
+  // issue cursor of the stage stream: (itile, ikt) is the next stage to fetch
+  int itile = t_beg + jb, ikt = 0;
+  if (itile < t_end) set_src(itile);
+  auto issue = [&](int slot) {
+    if (itile >= t_end) return;
+    char* as = smem + slot * STAGE;
+    const int k0 = ikt * BKE;
+#pragma unroll
+    for (int j = 0; j < APW; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + A_BYTES + (wave * BPW + j) * 1024), 16, 0, 0);
+    if (++ikt == nk) {
+      ikt = 0;
+      itile += nbx;
+      if (itile < t_end) set_src(itile);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+  int slot = 0;                                     // ring slot of the stage being computed
+  for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
+    const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
+    const bool last_tile = tile + nbx >= t_end;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int kt = 0; kt < nk; ++kt) {
+      // This wave's part of the stage has landed once at most the NS-2 following stages' instructions are outstanding (fewer at
+      // the end of the stream; the epilogue's stores, issued later still, only make the wait stricter).  The barrier extends
+      // that to every wave's part and says every wave has finished with the slot that is refilled next.
+#ifdef FK_RING_PROBE_DRAIN         // probe builds: one stage in flight, as in the double-buffered kernels
+      vm_wait_barrier<0>();
+#else
+      const int after = last_tile ? nk - 1 - kt : NS;          // stages of the stream behind this one (NS = "plenty")
+      if (after >= NS - 2) vm_wait_barrier<(NS - 2) * PER>();
+      else if (NS == 4 && after == 1) vm_wait_barrier<PER>();
+      else vm_wait_barrier<0>();
+#endif
+      issue(slot == 0 ? NS - 1 : slot - 1);
+      const char* as = smem + slot * STAGE;
+      const char* bs = as + A_BYTES;
+#ifndef FK_RING_PROBE_NOMMA        // probe builds (tools/): fetch stream only
+#pragma unroll
+      for (int s = 0; s < SSTEPS; ++s) {
+        Frag<T> fa[MT], fb[2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = wm * WM + i * 32 + li;
+          fa[i].v = *reinterpret_cast<const bf16x8*>(as + ring_off<RB>(row, 2 * s + lh));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = wn * 64 + j * 32 + li;
+          fb[j].v = *reinterpret_cast<const bf16x8*>(bs + ring_off<RB>(row, 2 * s + lh));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+      }
+#endif
+      slot = slot == NS - 1 ? 0 : slot + 1;
+    }
+    const int done = slot == 0 ? NS - 1 : slot - 1;  // slot of the tile's last stage: the staging area once every wave has read it
+    asm volatile("s_barrier" ::: "memory");
+    char* stg = wave < R::IN_SLOT ? smem + done * STAGE + wave * 8192 : smem + NS * STAGE + (wave - R::IN_SLOT) * 8192;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
+      nt_epilogue<T, TO, true, 1>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
+    }
+  }
+}
+
+template <typename TO, int BN_, int RB, int NS>
+static void launch_ring(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
+  using R = Ring<BN_, RB, NS>;
+  const int64_t nt = fk_cdiv(M, R::BM_) * (N / BN_);
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<TO, BN_, RB, NS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS) == hipSuccess);
+  (void)once;
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<TO, BN_, RB, NS>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R::LDS, s, p);
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 template <typename T> struct TNT;
 template <> struct TNT<bf16_t> { static constexpr int BKM = 64, ROWB = 256, CHUNKS = 16, STEPS = 4; };
@@ -630,16 +778,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs p) {
   }
 }
 
-// Large-tile weight-gradient kernel (bf16): 384 (A columns) x 128 (B columns) output tile per 8-wave block, 64 rows of m per
-// stage, both operands brought in by LDS-DMA (a 64 KiB stage, double buffered, one block per CU).  Why not the 128x128
+// Large-tile weight-gradient kernel (bf16): 384 (A columns) x 128 (B columns) output tile per 8-wave block, 32 rows of m per
+// stage, both operands brought in by LDS-DMA (32-KiB stages in a 4-slot ring, three in flight, one block per CU).  Why not the 128x128
 // register-staged kernel above: its m-loop runs one 0.3 us k-tile ahead of loads that take 1-3 us, and every staged byte pays
 // the ~79 B/clk ds_write path; here a stage carries 2 x 24 MFMAs per SIMD (~1 us) and nothing goes through ds_write.
-// Images are [64 m][row bytes] (A 768 B, B 256 B) with the 64-B granule swizzle of tn_off_bf16 inside every 256-B group,
+// Images are [32 m][row bytes] (A 768 B, B 256 B) with the 64-B granule swizzle of tn_off_bf16 inside every 256-B group,
 // applied on the DMA *source* column (the LDS side of an LDS-DMA is lane-linear).  Wave w: rows 96*(w>>1) of the tile's A
 // columns (3 MFMA tiles) x columns 64*(w&1) (2 tiles).  Requires M % 64 == 0, N1 % 384 == 0, N2 % 128 == 0.
-constexpr int TG_A = 384, TG_B = 128, TG_K = 64;
+constexpr int TG_A = 384, TG_B = 128, TG_K = 32;               // 32-row k-stages (32 KiB)
+#ifndef FK_TG_NS
+#define FK_TG_NS 4
+#endif
+constexpr int TG_NS = FK_TG_NS;                           // ring slots: TG_NS - 1 stages in flight
 constexpr int TG_A_ROW = TG_A * 2, TG_B_ROW = TG_B * 2;
-constexpr int TG_A_BYTES = TG_K * TG_A_ROW, TG_B_BYTES = TG_K * TG_B_ROW, TG_STAGE = TG_A_BYTES + TG_B_BYTES;   // 48 + 16 KiB
+constexpr int TG_A_BYTES = TG_K * TG_A_ROW, TG_B_BYTES = TG_K * TG_B_ROW, TG_STAGE = TG_A_BYTES + TG_B_BYTES;   // 24 + 8 KiB
 
 template <int PITCH> FK_DEV int tg_off(int row, int bytecol) {
   return row * PITCH + (bytecol & ~255) + ((((bytecol >> 6) ^ row) & 3) << 6) + (bytecol & 63);
@@ -680,17 +832,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
   const int nk = (mend - mbeg) / TG_K;
 
   // per-lane DMA sources: piece q of an image = LDS bytes [1024 q, 1024 q + 1024), lane l -> 16 B at 1024 q + 16 l
-  const T* srcA[6];
-  const T* srcB[2];
+  constexpr int APW = TG_A_BYTES / 8192, BPW = TG_B_BYTES / 8192, PER = APW + BPW;     // 3 + 1 LDS-DMA instructions per wave and stage
+  const T* srcA[APW];
+  const T* srcB[BPW];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int o = (wave * 6 + j) * 1024 + lane * 16, row = o / TG_A_ROW, bc = o % TG_A_ROW;
+  for (int j = 0; j < APW; ++j) {
+    const int o = (wave * APW + j) * 1024 + lane * 16, row = o / TG_A_ROW, bc = o % TG_A_ROW;
     const int sc = (bc & ~255) + ((((bc >> 6) ^ row) & 3) << 6) + (bc & 63);
     srcA[j] = (const T*)p.A + (int64_t)(mbeg + row) * p.lda + a0 + sc / 2;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int o = (wave * 2 + j) * 1024 + lane * 16, row = o / TG_B_ROW, bc = o % TG_B_ROW;
+  for (int j = 0; j < BPW; ++j) {
+    const int o = (wave * BPW + j) * 1024 + lane * 16, row = o / TG_B_ROW, bc = o % TG_B_ROW;
     const int sc = ((((bc >> 6) ^ row) & 3) << 6) + (bc & 63);
     srcB[j] = (const T*)p.B + (int64_t)(mbeg + row) * p.ldb + b0 + sc / 2;
   }
@@ -698,13 +851,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
   auto stage = [&](int buf) {
     char* as = smem + buf * TG_STAGE;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)srcA[j], (lds_void_t*)(as + (wave * 6 + j) * 1024), 16, 0, 0);
+    for (int j = 0; j < APW; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)srcA[j], (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
       srcA[j] += astep;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)srcB[j], (lds_void_t*)(as + TG_A_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
+    for (int j = 0; j < BPW; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)srcB[j], (lds_void_t*)(as + TG_A_BYTES + (wave * BPW + j) * 1024), 16, 0, 0);
       srcB[j] += bstep;
     }
   };
@@ -727,11 +880,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  if (nk > 0) stage(0);
-  __syncthreads();
+  // The k-stages stream through TG_NS ring slots with counted waits (see gemm_nt_ring_kernel): stage kt+TG_NS-1 is issued when stage kt
+  // starts computing; `s_waitcnt vmcnt((TG_NS-2) PER)` = this wave's part of stage kt has landed, the barrier = everybody's has and
+  // everybody is done reading the slot refilled next.
+#pragma unroll
+  for (int s = 0; s < TG_NS - 1; ++s)
+    if (s < nk) stage(s);
+  int slot = 0;                                     // ring slot of the stage being computed
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage((kt + 1) & 1);
-    const unsigned bo = (kt & 1) * TG_STAGE;
+    const int after = nk - 1 - kt;                  // stages behind this one: min(after, TG_NS - 2) of them are in flight
+    if (after >= TG_NS - 2) vm_wait_barrier<(TG_NS - 2) * PER>();
+    else if (after == 3) vm_wait_barrier<3 * PER>();
+    else if (after == 2) vm_wait_barrier<2 * PER>();
+    else if (after == 1) vm_wait_barrier<PER>();
+    else vm_wait_barrier<0>();
+    if (kt + TG_NS - 1 < nk) stage(slot == 0 ? TG_NS - 1 : slot - 1);
+    const unsigned bo = slot * TG_STAGE;
+    slot = slot == TG_NS - 1 ? 0 : slot + 1;
     Frag<T> f0[5], f1[5];
 #define TG_LOAD(F, S)                                                      \
     tg_frag<TG_A_ROW, S>(F[0], fbase[0] + bo); tg_frag<TG_A_ROW, S>(F[1], fbase[1] + bo); \
@@ -744,17 +909,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
     TG_LOAD(f1, 1)
     lgkm_wait<10>();
     TG_MMA(f0)
-    TG_LOAD(f0, 2)
-    lgkm_wait<10>();
-    TG_MMA(f1)
-    TG_LOAD(f1, 3)
-    lgkm_wait<10>();
-    TG_MMA(f0)
     lgkm_wait<0>();
     TG_MMA(f1)
 #undef TG_LOAD
 #undef TG_MMA
-    __syncthreads();
   }
 
   float* out = (p.nsplit > 1) ? p.ws + (int64_t)split * p.N1 * p.N2 : p.C;
@@ -868,7 +1026,7 @@ bool tn_big_ok(int64_t M, int64_t N1, int64_t N2, int dtype) {
 int tn_big_splits(int64_t M, int64_t N1, int64_t N2) {
   const int64_t tiles = (N1 / TG_A) * (N2 / TG_B);
   int64_t want = 256 / tiles;                               // one wave of blocks, one block per CU
-  const int64_t maxs = M / (TG_K * 8);                      // >= 8 k-tiles per split
+  const int64_t maxs = M / 512;                             // >= 512 rows (16 k-stages) per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   return (int)want;
@@ -913,7 +1071,21 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   const size_t sh = 4 * TILE_BYTES;
   hipStream_t s = (hipStream_t)stream;
   const bool glds = dtype == FK_BF16 && (K % 64 == 0);
-  if (glds && M >= 4096 && N % 256 == 0 && vec_epi) {         // large projections: 256 x 256 tiles, 1 block per CU (the 256x128
+  static const bool no_ring = getenv("FK_NT_NO_RING") != nullptr;       // tuning knob: the double-buffered kernels instead
+  const bool wide = glds && M >= 4096 && vec_epi && !no_ring;
+  if (wide && N % 256 == 0 && mode != 2) {      // 256 x 256 ring (the fused SwiGLU-backward epilogue streams h13 itself and measured
+                                                // 3 % slower on it: that one stays on the double-buffered kernel below)
+    if (out_dtype == FK_BF16) launch_ring<bf16_t, 256, 64, 4>(p, M, N, s); else launch_ring<float, 256, 64, 4>(p, M, N, s);
+    FK_CHECK_LAUNCH(name);
+    return FK_OK;
+  }
+  if (wide && N % 128 == 0 && N % 256 != 0) {   // N = 384 / 1152: 256 x 128 ring
+    if (out_dtype == FK_BF16) launch_ring<bf16_t, 128, 128, 3>(p, M, N, s); else launch_ring<float, 128, 128, 3>(p, M, N, s);
+    FK_CHECK_LAUNCH(name);
+    return FK_OK;
+  }
+  if (glds && M >= 4096 && N % 256 == 0 && vec_epi) {
+        // large projections: 256 x 256 tiles, 1 block per CU (the 256x128
                                                                 // variant measured slower than 128x128 at N = 384)
     const int64_t nt = fk_cdiv(M, 256) * (N / 256);
     dim3 bgrid((unsigned)(nt < 256 ? nt : 256)), bblock(512);
@@ -987,10 +1159,10 @@ int fk_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
   dim3 grid((unsigned)(fk_cdiv(N1, BM) * fk_cdiv(N2, BN) * ns)), block(NTHREADS);
   hipStream_t s = (hipStream_t)stream;
   if (big) {
-    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TG_STAGE) == hipSuccess);
+    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TG_NS * TG_STAGE) == hipSuccess);
     (void)once;
     dim3 bgrid((unsigned)((N1 / TG_A) * (N2 / TG_B) * ns));
-    hipLaunchKernelGGL(gemm_tn_big_kernel, bgrid, dim3(512), 2 * TG_STAGE, s, p);
+    hipLaunchKernelGGL(gemm_tn_big_kernel, bgrid, dim3(512), TG_NS * TG_STAGE, s, p);
   } else if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 4 * TILE_BYTES, s, p);
   else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 4 * TILE_BYTES, s, p);
   FK_CHECK_LAUNCH("fk_gemm_tn");
