@@ -108,9 +108,10 @@ def test_gemm_tn(K, dtype, shape):
     close(acc, ref + 1, torch.float32, atol32=2e-3 if dtype == torch.float32 else 5e-2 * math.sqrt(M / 1000), rtol32=1e-4 if dtype == torch.float32 else 2e-2)
 
 
-@pytest.mark.parametrize("shape", [(16384 + 192, 384, 256), (24576, 768, 128), (16384, 384, 384)])
+@pytest.mark.parametrize("shape", [(16384 + 192, 384, 256), (24576, 768, 128), (16384, 384, 384), (16384 + 32, 384, 128), (16384 + 96, 768, 256)])
 def test_gemm_tn_large_tile_exact_integers(K, shape):
-    """the 384x128-tile LDS-DMA weight-gradient kernel (bf16, M % 64 == 0, N1 % 384 == 0, N2 % 128 == 0): asymmetric integer
+    """the 384x128-tile LDS-DMA weight-gradient kernel (bf16, M % 32 == 0, N1 % 384 == 0, N2 % 128 == 0; 32-row stages in a 4-slot
+    ring, so splits with an odd and an even number of stages and fewer stages than slots in the tail are all here): asymmetric integer
     operands make the result exact, so any fragment / swizzle / split mix-up shows up as a hard mismatch; strided views too."""
     M, N1, N2 = shape
     g = torch.Generator().manual_seed(5)
@@ -127,6 +128,55 @@ def test_gemm_tn_large_tile_exact_integers(K, shape):
     acc = torch.full((N1, N2), 3.0, device="cuda")
     K.gemm_tn(ad, bd, out=acc, accumulate=True)
     assert torch.equal(acc.cpu(), ref + 3)
+
+
+RING_SHAPES = [(4096, 384, 64), (4168, 128, 128), (8200, 1152, 384), (4104, 256, 64), (70000, 256, 128), (66000, 384, 192),
+               (4096, 512, 128), (33000, 768, 64)]
+
+
+@pytest.mark.parametrize("shape", RING_SHAPES)
+def test_gemm_nt_ring_kernels_exact_integers(K, shape):
+    """the ring-buffered wide-projection kernels (bf16, M >= 4096, N % 128 == 0, K % 64 == 0): one and several tiles per persistent
+    block (the stage stream crosses tile boundaries), a single k-stage, fewer stages than ring slots, ragged last row tile, 256- and
+    128-column tiles.  Integer operands make every sum exact: fp32 output must be bit-equal to the reference, bf16 output to its
+    single rounding; bias / residual / periodic residual ride on the same epilogue."""
+    M, N, Kd = shape
+    g = torch.Generator().manual_seed(7)
+    a = torch.randint(-2, 3, (M, Kd + 8), generator=g).float()
+    w = torch.randint(-2, 3, (N, Kd), generator=g).float()
+    a[:, 5] += (torch.arange(M) % 7).float()
+    w[:, 2] += (torch.arange(N) % 3).float()
+    ad, wd = dev(a, torch.bfloat16)[:, :Kd], dev(w, torch.bfloat16)          # A with row stride Kd + 8
+    ref = a[:, :Kd] @ w.t()
+    assert float(ref.abs().max()) < 2 ** 24
+    assert torch.equal(K.gemm_nt(ad, wd, out_dtype=torch.float32).cpu(), ref)
+    assert torch.equal(K.gemm_nt(ad, wd).float().cpu(), ref.to(torch.bfloat16).float())
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    res = torch.randint(-4, 5, (M, N), generator=g).float()
+    got = K.gemm_nt(ad, wd, bias=dev(bias, torch.bfloat16), residual=dev(res, torch.bfloat16), out_dtype=torch.float32)
+    assert torch.equal(got.cpu(), ref + bias + res)
+    tab = torch.randint(-4, 5, (24, N), generator=g).float()
+    got = K.gemm_nt(ad, wd, residual=dev(tab, torch.bfloat16), res_rows=24)
+    assert torch.equal(got.float().cpu(), (ref + tab[torch.arange(M) % 24]).to(torch.bfloat16).float())
+
+
+def test_gemm_nt_ring_fused_epilogues_match_small_kernel(K):
+    """SwiGLU-forward and RoPE epilogues on the ring kernels (M >= 4096) against the same rows computed in < 4096-row pieces,
+    which take the 128x128 kernel: bit-identical (same accumulation order over k, same epilogue code)."""
+    M, d, H = 4096 + 520, 128, 256
+    x, w13 = dev(rnd(M, d, seed=1), torch.bfloat16), dev(rnd(2 * H, d, seed=2, scale=0.2), torch.bfloat16)
+    h13, gq = K.gemm_nt_swiglu(x, w13)
+    for lo in range(0, M, 2000):
+        h, g2 = K.gemm_nt_swiglu(x[lo:lo + 2000], w13)
+        assert torch.equal(h13[lo:lo + 2000], h) and torch.equal(gq[lo:lo + 2000], g2)
+    T, D, Hh = 577, 32, 4                                      # M = 8 * 577 = 4616 rows, N = 3 * 128 = 384
+    ang = R.rope_angles(D, 640, 10000.0)
+    table = dev(torch.stack([torch.cos(ang), torch.sin(ang)], -1).contiguous())
+    xq, wq = dev(rnd(8 * T, d, seed=3), torch.bfloat16), dev(rnd(3 * Hh * D, d, seed=4, scale=0.2), torch.bfloat16)
+    full = K.gemm_nt_rope(xq, wq, None, table, T, 10, D, 2 * Hh * D)
+    for b in range(0, 8, 4):
+        part = K.gemm_nt_rope(xq[b * T:(b + 4) * T], wq, None, table, T, 10, D, 2 * Hh * D)
+        assert torch.equal(full[b * T:(b + 4) * T], part)
 
 
 @pytest.mark.parametrize("dtype", DT)
