@@ -503,9 +503,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
 // through NS ring slots: stage g+NS-1 is issued when stage g starts computing, the wait before stage g is the counted
 // `s_waitcnt vmcnt((NS-2) PER)` (vmcnt retires in order; PER = LDS-DMA instructions per wave and stage), and the stream runs across
 // tile boundaries, so the next tile's first stages land during the epilogue.  The epilogue stages through the slot just computed
-// plus the LDS above the ring.  Two shapes, both 8 waves and the whole 160 KiB of a CU:
-//   N % 256 == 0 : 256 x 256 tile, 32-element k-stages (64-B image rows), NS = 4  (3 x 32 KiB in flight)
-//   N % 128 == 0 : 256 x 128 tile, 64-element k-stages (128-B image rows), NS = 3 (2 x 48 KiB in flight)
+// plus the LDS above the ring.  Shapes, all 8 waves and the whole 160 KiB of a CU:
+//   N = 384-class : gemm_nt_ring_kernel<128, 128, 3>: 256 x 128 tile, 64-element k-stages (128-B image rows), 2 x 48 KiB in flight
+//   N >= 1024     : gemm_nt_ring2_kernel below: 256 x 256 tile with separate A / B rings
+// (a 256 x 256 tile with 32-element stages, <256, 64, 4>, also works but its 64-byte requests fetch 1.4x slower per byte).
 template <int N> FK_DEV void vm_wait_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
@@ -632,6 +633,121 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
       nt_epilogue<T, TO, true, 1>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
     }
   }
+}
+
+// 256 x 256 tile with full-line (128-B) requests: three slots do not fit (3 x 64 KiB), so the operands get rings of different depth,
+// A (activations, streamed from HBM) three 32-KiB slots and B (weights, L2-resident) two.  Per step the wave issues B(g+1) and then
+// A(g+2); the wait before stage g is vmcnt(APW): everything but the 4 newest instructions, i.e. all of A(g) and B(g), has landed
+// and A(g+1) stays in flight across the barrier, so the memory pipe never drains.  The epilogue stages through the A and B slots
+// just computed (4 waves each).  LDS = 96 + 64 KiB.
+constexpr int R2_A = 256 * ROW_BYTES, R2_LDS = 5 * R2_A;
+
+template <typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
+  using T = bf16_t;
+  constexpr int BM_ = 256, BN_ = 256, APW = 4, BPW = 4, WM = 128, MT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto aslot = [&](int i) -> char* { return smem + i * R2_A; };
+  auto bslot = [&](int i) -> char* { return smem + (3 + i) * R2_A; };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
+  const int ntn = (p.N + BN_ - 1) / BN_;
+  const int ntiles = ((p.M + BM_ - 1) / BM_) * ntn;
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = (nb + 7 - xcd) >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int t_beg = xcd * q8 + min(xcd, r8), t_end = t_beg + q8 + (xcd < r8 ? 1 : 0);
+  const int nk = p.K / 64;
+
+  const T* srcA[APW];
+  const T* srcB[BPW];
+  auto set_a = [&](int tile) {
+    const int m0 = (tile / ntn) * BM_;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const int row = (wave * APW + j) * 8 + (lane >> 3);
+      srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  auto set_b = [&](int tile) {
+    const int n0 = (tile % ntn) * BN_;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      const int row = (wave * BPW + j) * 8 + (lane >> 3);
+      srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  // two issue cursors over the same stage stream: A runs two stages ahead of the compute, B one
+  int atile = t_beg + jb, akt = 0, btile = atile, bkt = 0;
+  if (atile < t_end) { set_a(atile); set_b(btile); }
+  auto issue_a = [&](int slot) {
+    if (atile >= t_end) return;
+    char* as = aslot(slot);
+#pragma unroll
+    for (int j = 0; j < APW; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + akt * 64), (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
+    if (++akt == nk) { akt = 0; atile += nbx; if (atile < t_end) set_a(atile); }
+  };
+  auto issue_b = [&](int slot) {
+    if (btile >= t_end) return;
+    char* bs = bslot(slot);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + bkt * 64), (lds_void_t*)(bs + (wave * BPW + j) * 1024), 16, 0, 0);
+    if (++bkt == nk) { bkt = 0; btile += nbx; if (btile < t_end) set_b(btile); }
+  };
+  issue_a(0);
+  issue_b(0);
+  issue_a(1);
+  int sa = 0, sb = 0;                               // slots of the stage being computed
+  for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
+    const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
+    const bool last_tile = tile + nbx >= t_end;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (last_tile && kt == nk - 1) vm_wait_barrier<0>(); else vm_wait_barrier<APW>();
+      issue_b(sb ^ 1);
+      issue_a(sa == 0 ? 2 : sa - 1);
+      const char* as = aslot(sa);
+      const char* bs = bslot(sb);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> fa[MT], fb[2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) nt_frag<T>(fa[i], as, wm * WM + i * 32 + li, s, lh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+      }
+      sa = sa == 2 ? 0 : sa + 1;
+      sb ^= 1;
+    }
+    asm volatile("s_barrier" ::: "memory");          // every wave has read the last stage: its two slots become the staging area
+    char* stg = wave < 4 ? aslot(sa == 0 ? 2 : sa - 1) + wave * 8192 : bslot(sb ^ 1) + (wave - 4) * 8192;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
+      nt_epilogue<T, TO, true, 1>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
+    }
+  }
+}
+
+template <typename TO>
+static void launch_ring2(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
+  const int64_t nt = fk_cdiv(M, 256) * fk_cdiv(N, 256);
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring2_kernel<TO>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS) == hipSuccess);
+  (void)once;
+  hipLaunchKernelGGL((gemm_nt_ring2_kernel<TO>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R2_LDS, s, p);
 }
 
 template <typename TO, int BN_, int RB, int NS>
@@ -1073,13 +1189,13 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   const bool glds = dtype == FK_BF16 && (K % 64 == 0);
   static const bool no_ring = getenv("FK_NT_NO_RING") != nullptr;       // tuning knob: the double-buffered kernels instead
   const bool wide = glds && M >= 4096 && vec_epi && !no_ring;
-  if (wide && N % 256 == 0 && mode != 2) {      // 256 x 256 ring (the fused SwiGLU-backward epilogue streams h13 itself and measured
-                                                // 3 % slower on it: that one stays on the double-buffered kernel below)
-    if (out_dtype == FK_BF16) launch_ring<bf16_t, 256, 64, 4>(p, M, N, s); else launch_ring<float, 256, 64, 4>(p, M, N, s);
+  if (wide && (N % 256 == 0 || (N % 128 == 0 && N >= 1024))) {   // 256 x 256 tiles, split A/B rings (N = 1152: the last column tile is
+                                                                  // half empty, still 4 % faster than 256 x 128 tiles)
+    if (out_dtype == FK_BF16) launch_ring2<bf16_t>(p, M, N, s); else launch_ring2<float>(p, M, N, s);
     FK_CHECK_LAUNCH(name);
     return FK_OK;
   }
-  if (wide && N % 128 == 0 && N % 256 != 0) {   // N = 384 / 1152: 256 x 128 ring
+  if (wide && N % 128 == 0) {                  // N = 128 / 384 / 640 / 896: 256 x 128 ring
     if (out_dtype == FK_BF16) launch_ring<bf16_t, 128, 128, 3>(p, M, N, s); else launch_ring<float, 128, 128, 3>(p, M, N, s);
     FK_CHECK_LAUNCH(name);
     return FK_OK;
