@@ -1188,7 +1188,8 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   hipStream_t s = (hipStream_t)stream;
   const bool glds = dtype == FK_BF16 && (K % 64 == 0);
   static const bool no_ring = getenv("FK_NT_NO_RING") != nullptr;       // tuning knob: the double-buffered kernels instead
-  const bool wide = glds && M >= 4096 && vec_epi && !no_ring;
+  static const int ring_min = getenv("FK_NT_RING_MIN_TILES") ? atoi(getenv("FK_NT_RING_MIN_TILES")) : 0;
+  const bool wide = glds && M >= 4096 && vec_epi && !no_ring && fk_cdiv(M, 256) * fk_cdiv(N, 256) >= ring_min;
   if (wide && (N % 256 == 0 || (N % 128 == 0 && N >= 1024))) {   // 256 x 256 tiles, split A/B rings (N = 1152: the last column tile is
                                                                   // half empty, still 4 % faster than 256 x 128 tiles)
     if (out_dtype == FK_BF16) launch_ring2<bf16_t>(p, M, N, s); else launch_ring2<float>(p, M, N, s);

@@ -271,16 +271,14 @@ class GraphedTrainStep:
     rate changes every step) runs eagerly after each replay.  For the small configurations (gpt2-nano, SimpleMAE B=32)
     a step is ~300 launches of a few microseconds each and the Python/ctypes launch path, not the GPU, sets the step
     time; replaying a graph removes it.  Requirements: static batch shape, one process (the gradient exchange is
-    hook-driven and not captured), grad_accum == 1, a forward without host-side randomness, no weight-gradient side
-    stream.  Same numbers as ``train_step``: the captured kernels are the ones the eager step launches."""
+    hook-driven and not captured), grad_accum == 1, a forward without host-side randomness.  With the weight-gradient side
+    stream on (FusedAdamW(overlap_wgrad=True)) the dW GEMMs become a parallel branch of the graph.  Same numbers as ``train_step``: the captured kernels are the ones the eager step launches."""
 
     def __init__(self, model, batch, optimizer: FusedAdamW, cfg: TrainConfig, scheduler=None, warmup: int = 2):
         if _dist_info()[1] != 1:
             raise RuntimeError("GraphedTrainStep is single-process: the bucketed gradient exchange is not captured")
         if cfg.grad_accum != 1:
             raise RuntimeError("GraphedTrainStep needs grad_accum == 1")
-        if E.wgrad_stream() is not None:
-            raise RuntimeError("GraphedTrainStep needs the weight-gradient side stream off")
         self.model, self.optimizer, self.cfg = model, optimizer, cfg
         self.get_lr = scheduler or init_lr_scheduler(cfg)
         self.static = tuple(t.clone() if torch.is_tensor(t) else t for t in batch)
@@ -302,6 +300,9 @@ class GraphedTrainStep:
         inputs, labels, date_info = self.static
         loss, _ = self.model(inputs, labels, date_info=date_info)
         loss.backward()
+        side = E.wgrad_stream()
+        if side is not None:                            # join the weight-gradient branch: a captured graph must end on one stream
+            torch.cuda.current_stream().wait_stream(side)
         return loss.detach()
 
     def __call__(self, batch, step: int):

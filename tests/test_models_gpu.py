@@ -611,7 +611,8 @@ def test_vq_plus_brainformer_pipeline_bf16():
         fa.set_compute_dtype("fp32")
 
 
-def test_graphed_train_step_is_bit_identical_to_eager():
+@pytest.mark.parametrize("overlap", [False, True], ids=["one-stream", "wgrad-branch"])
+def test_graphed_train_step_is_bit_identical_to_eager(overlap):
     """train_utils.GraphedTrainStep (forward + backward replayed from one hipGraph, update eager) against train_step on
     the same seeded batches with a cosine schedule: same losses and same parameters bit for bit after 5 steps; a batch of
     another shape is refused."""
@@ -632,7 +633,7 @@ def test_graphed_train_step_is_bit_identical_to_eager():
         for graphed in (False, True):
             torch.manual_seed(0)
             m = bf.BrainFormer(cfg).cuda()
-            opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=1e-2, grad_clip=1.0)
+            opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=1e-2, grad_clip=1.0, overlap_wgrad=graphed and overlap)
             if graphed:
                 step = tu.GraphedTrainStep(m, batches[0], opt, tc)
                 losses = [float(step(b, i)) for i, b in enumerate(batches)]
@@ -645,4 +646,6 @@ def test_graphed_train_step_is_bit_identical_to_eager():
         assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
         assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
     finally:
+        from frankenstein_amd import engine as E
+        E.enable_wgrad_stream(False)
         fa.set_compute_dtype("fp32")
