@@ -670,8 +670,8 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   };
   auto store_stats = [&](int buf) {
     if (tid < TQ) {
-      stats[buf * 2 * TQ + tid] = st_ok ? st_l * LOG2E : INFINITY;
-      stats[buf * 2 * TQ + TQ + tid] = st_ok ? st_d : 0.0f;
+      stats[buf * 2 * TQ + tid] = st_ok ? -(st_l * LOG2E) : -INFINITY;   // staged NEGATED: phase 2 then needs no per-element sign flips
+      stats[buf * 2 * TQ + TQ + tid] = st_ok ? -st_d : 0.0f;
     }
   };
   if (ntiles > 0) {
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
           for (int j = 0; j < 4; j += 2) {
             const int r = 4 * g + j;
             f32x2 x = {sc[u][r], sc[u][r + 1]}, d = {dp[u][r], dp[u][r + 1]};
-            const f32x2 nl = {-l4[j], -l4[j + 1]}, nd = {-d4[j], -d4[j + 1]};
+            const f32x2 nl = {l4[j], l4[j + 1]}, nd = {d4[j], d4[j + 1]};      // (-lse2, -delta)
             x = __builtin_elementwise_fma(x, c2, nl);
             x[0] = __builtin_amdgcn_exp2f(x[0]);
             x[1] = __builtin_amdgcn_exp2f(x[1]);
@@ -762,11 +762,11 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j;
-            float pv = __builtin_amdgcn_exp2f(sc[u][r] * c - l4[j]);
+            float pv = __builtin_amdgcn_exp2f(sc[u][r] * c + l4[j]);
             const int q = qb + 32 * u + acc_row(r, lh);
             if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))))) pv = 0.0f;
             sc[u][r] = pv;
-            dp[u][r] = pv * (dp[u][r] - d4[j]);
+            dp[u][r] = pv * (dp[u][r] + d4[j]);
           }
         }
       }
