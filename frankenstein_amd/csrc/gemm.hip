@@ -64,7 +64,7 @@ template <typename T> FK_DEV float sigmoid_f(float x) {
 }
 
 // Epilogue shared by the NT kernels: acc are C^T tiles (lane = output row m, registers = 4 consecutive n).
-template <typename T, typename TO, bool VEC_ONLY = false, int NI = 2>
+template <typename T, typename TO, bool VEC_ONLY = false, int NI = 2, bool PRE_RES = false>
 FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mrow0, int ncol0, int lane, bool sync) {
   // acc = one wave's (32 NI) x 64 sub-tile whose top-left output element is (mrow0, ncol0); stg = that wave's 8 NI KiB of LDS
   const int li = lane & 31, lh = lane >> 5;
@@ -82,6 +82,26 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     // The slice is reused by back-to-back calls (one per 32-row group): the previous call's last ds_read_b128s must have
     // returned before this call's ds_write_b128s are issued.  Without the wait, rows 30/31 of a group (the last lane groups of
     // the last pass) occasionally came back with the NEXT group's values — found by a run-to-run determinism check at full size.
+    const int col = (lane & 7) * 8, nb = ncol0 + col;
+    const bool col_ok = nb < p.N;                   // N % 8 == 0 on this path
+    const int r0 = lane >> 3, mb = mrow0 + r0;      // this lane's row in pass 0; pass ps handles row mb + 8 * ps
+    // Residual rows of the 4 passes (bf16, 32-row slices): fetched BEFORE the staging writes so that their latency hides behind the
+    // LDS round trip instead of being paid once per pass of the rolled sweep (+45 us per N = 384 GEMM of the cfg2 step otherwise).
+    constexpr bool PRE = PRE_RES && (NI == 1) && sizeof(T) == 2;   // (on the 256 x 256 kernel the extra live registers cost the fused epilogues 10 %: opt-in)
+    bf16x8 rq0 = {}, rq1 = {}, rq2 = {}, rq3 = {};
+    if constexpr (PRE) {
+      if (res) {
+        int rr = p.res_rows > 0 ? mb % (int)p.res_rows : mb;
+        auto fetch = [&](int ps) {
+          bf16x8 r = {};
+          if (mb + 8 * ps < p.M && col_ok) r = *reinterpret_cast<const bf16x8*>(res + (int64_t)rr * p.ldr + nb);
+          rr += 8;
+          if (p.res_rows > 0) { while (rr >= (int)p.res_rows) rr -= (int)p.res_rows; }
+          return r;
+        };
+        rq0 = fetch(0); rq1 = fetch(1); rq2 = fetch(2); rq3 = fetch(3);
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -95,9 +115,6 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     // The sweep is VALU-bound (a wave64 VALU op holds the SIMD for 4 cycles and no MFMA runs beside it), so everything
     // row- or column-invariant is hoisted: one division per sub-tile, pointer increments per pass, uniform branches
     // around absent bias / residual / RoPE work, and the bf16 mode uses v_rcp_f32 for the sigmoid.
-    const int col = (lane & 7) * 8, nb = ncol0 + col;
-    const bool col_ok = nb < p.N;                   // N % 8 == 0 on this path
-    const int r0 = lane >> 3, mb = mrow0 + r0;      // this lane's row in pass 0; pass ps handles row mb + 8 * ps
     float bv[8];
     if (bias && col_ok) {
 #pragma unroll
@@ -105,7 +122,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     }
     // residual row of pass 0 (periodic residual: row m % res_rows, advanced by 8 per pass with wrap)
     int rr = 0;
-    if (res) rr = p.res_rows > 0 ? mb % (int)p.res_rows : mb;
+    if (res && !PRE) rr = p.res_rows > 0 ? mb % (int)p.res_rows : mb;
     // RoPE: (cos, sin) pairs of token (m % T) of sample (m / T) for the 4 complex pairs of this lane's 8 columns
     const float* tb = nullptr;
     int tt = 0;
@@ -128,7 +145,10 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
         }
         if (res) {
           const T* rp = res + (int64_t)rr * p.ldr + nb;
-          if constexpr (sizeof(T) == 2) {
+          if constexpr (PRE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rq0[e];
+          } else if constexpr (sizeof(T) == 2) {
             bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rp);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
@@ -144,8 +164,10 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float re = v[2 * j], im = v[2 * j + 1];
-            v[2 * j] = re * cs[2 * j] - im * cs[2 * j + 1];
-            v[2 * j + 1] = re * cs[2 * j + 1] + im * cs[2 * j];
+            // explicit fma shape: with -ffp-contract=fast hipcc otherwise picks which product is fused per instantiation, and the
+            // kernels would differ in the last bit (the GPU suite compares the ring-buffered and the small kernel bit for bit)
+            v[2 * j] = __builtin_fmaf(re, cs[2 * j], -(im * cs[2 * j + 1]));
+            v[2 * j + 1] = __builtin_fmaf(re, cs[2 * j + 1], im * cs[2 * j]);
           }
         }
         if (p.mode == 2) {
@@ -220,8 +242,12 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
       }
       // advance the row-dependent cursors by 8 rows
       if (res) {
-        rr += 8;
-        if (p.res_rows > 0) { while (rr >= (int)p.res_rows) rr -= (int)p.res_rows; }
+        if constexpr (PRE) {
+          rq0 = rq1; rq1 = rq2; rq2 = rq3;             // next pass's prefetched row
+        } else {
+          rr += 8;
+          if (p.res_rows > 0) { while (rr >= (int)p.res_rows) rr -= (int)p.res_rows; }
+        }
       }
       if (do_rope) {
         tt += 8;
@@ -630,7 +656,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
-      nt_epilogue<T, TO, true, 1>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
+      if (BN_ == 128 && p.res) nt_epilogue<T, TO, true, 1, true>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
+      else nt_epilogue<T, TO, true, 1, false>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
     }
   }
 }
