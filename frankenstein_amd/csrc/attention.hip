@@ -164,6 +164,36 @@ FK_DEV void dma_tile_bf16_d64(const bf16_t* base, int64_t rs, int row0, int nrow
   }
 }
 
+// The same loader as a cursor over consecutive tiles: the per-lane source pointers are computed once and advanced by ROWS rows per
+// tile (one 64-bit add per instruction instead of a clamp, two 32-bit multiplies and a 64-bit multiply-add, all quarter-rate VALU work
+// that sat in every tile of the hot loops); only a tile that reaches past `nrows` takes the clamping path above.  Used where registers
+// allow (dQ): the forward (128) and dK/dV (256) kernels sit exactly at their occupancy limits and the 4 cursor registers would spill.
+template <int ROWS, int NW = 4>
+struct DmaCursor {
+  static constexpr int PER_WAVE = ROWS / 8 / NW;
+  const bf16_t* src[PER_WAVE];                       // the only state: the caller passes the tile's row0 again (it has it anyway)
+  FK_DEV void init(const bf16_t* base, int64_t rs, int row0, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+      const int grp = wave * PER_WAVE + j, row = grp * 8 + (lane >> 3);
+      const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+      src[j] = base + (int64_t)(row0 + row) * rs + ((lane & 7) ^ f) * 8;
+    }
+  }
+  // fetch the tile at the cursor (rows row0 .. row0 + ROWS) into img and move the cursor one tile on
+  FK_DEV void next(const bf16_t* base, int64_t rs, int row0, int nrows, char* img, int wave, int lane) {
+    if (row0 + ROWS <= nrows) {                      // wave-uniform
+#pragma unroll
+      for (int j = 0; j < PER_WAVE; ++j) {
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src[j], (lds_void_t*)(img + (wave * PER_WAVE + j) * 1024), 16, 0, 0);
+        src[j] += (int64_t)ROWS * rs;
+      }
+    } else {
+      dma_tile_bf16_d64<ROWS, NW>(base, rs, row0, nrows, img, wave, lane);
+    }
+  }
+};
+
 // ---- global -> register -> LDS staging of a [ROWS][D] head tile -----------------------------------
 template <typename T, int D, int ROWS> struct Stager {
   using C = AT<T, D>;
@@ -508,10 +538,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
 
   constexpr bool DMA = Img<T, D>::SWZ;
   Stager<T, D, DMA ? 4 : BKV> sk, sv;
+  DmaCursor<BKV> kcur, vcur;
   if (ntiles > 0) {
     if constexpr (DMA) {
-      dma_tile_bf16_d64<BKV>((const bf16_t*)Kp, p.k_rs, 0, p.Nk, kimg(0), wave, lane);
-      dma_tile_bf16_d64<BKV>((const bf16_t*)Vp, p.v_rs, 0, p.Nk, vimg(0), wave, lane);
+      kcur.init((const bf16_t*)Kp, p.k_rs, 0, wave, lane);
+      vcur.init((const bf16_t*)Vp, p.v_rs, 0, wave, lane);
+      kcur.next((const bf16_t*)Kp, p.k_rs, 0, p.Nk, kimg(0), wave, lane);
+      vcur.next((const bf16_t*)Vp, p.v_rs, 0, p.Nk, vimg(0), wave, lane);
     } else {
       sk.load(Kp, p.k_rs, 0, p.Nk, tid);
       sv.load(Vp, p.v_rs, 0, p.Nk, tid);
@@ -530,8 +563,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
     const int kb = t * BKV;
     if (t + 1 < ntiles) {
       if constexpr (DMA) {
-        dma_tile_bf16_d64<BKV>((const bf16_t*)Kp, p.k_rs, kb + BKV, p.Nk, kimg((t + 1) & 1), wave, lane);
-        dma_tile_bf16_d64<BKV>((const bf16_t*)Vp, p.v_rs, kb + BKV, p.Nk, vimg((t + 1) & 1), wave, lane);
+        kcur.next((const bf16_t*)Kp, p.k_rs, kb + BKV, p.Nk, kimg((t + 1) & 1), wave, lane);
+        vcur.next((const bf16_t*)Vp, p.v_rs, kb + BKV, p.Nk, vimg((t + 1) & 1), wave, lane);
       } else {
         sk.load(Kp, p.k_rs, kb + BKV, p.Nk, tid);
         sv.load(Vp, p.v_rs, kb + BKV, p.Nk, tid);
