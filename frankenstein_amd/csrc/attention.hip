@@ -159,7 +159,10 @@ FK_DEV void dma_tile_bf16_d64(const bf16_t* base, int64_t rs, int row0, int nrow
     const int row = grp * 8 + (lane >> 3);
     const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
     const int ch = (lane & 7) ^ f;                     // logical chunk stored at physical chunk (lane & 7)
-    const bf16_t* src = base + (int64_t)min(row0 + row, nrows - 1) * rs + ch * 8;
+    // 32-bit element offset from the (wave-uniform) head base: one full-rate v_mad_u32_u24 instead of a 64-bit multiply, and the
+    // address goes out as SGPR base + VGPR offset.  launch_*() checks rows and row strides < 2^24.
+    const unsigned off = __umul24((unsigned)min(row0 + row, nrows - 1), (unsigned)rs) + (unsigned)(ch * 8);
+    const bf16_t* src = base + off;
     __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(img + grp * 1024), 16, 0, 0);
   }
 }
@@ -883,6 +886,12 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
   const int vec = dtype == FK_BF16 ? 8 : 4;
   for (int i = 0; i < nstr; ++i)
     FK_CHECK_ARG(strides[i] % vec == 0, "%s: strides must be multiples of %d elements (16 bytes)", name, vec);
+  if (dtype == FK_BF16 && D == 64) {          // the LDS-DMA tile loader addresses rows with 24-bit multiplies and 32-bit offsets
+    FK_CHECK_ARG(Nq < (1LL << 24) && Nk < (1LL << 24), "%s: bf16 D=64 path needs fewer than 2^24 rows", name);
+    for (int i = 1; i < nstr; i += 2)          // {batch stride, row stride} pairs: the row strides
+      FK_CHECK_ARG(strides[i] >= 0 && strides[i] < (1LL << 24) && strides[i] * (Nq > Nk ? Nq : Nk) < (1LL << 31),
+                   "%s: bf16 D=64 path needs row strides < 2^24 elements and a head slab < 2^31 elements", name);
+  }
   return FK_OK;
 }
 
