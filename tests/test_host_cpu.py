@@ -207,3 +207,22 @@ def test_public_surface_of_the_reference_modules_is_present():
         assert hasattr(bf.MAE, meth)
     assert len(du.DATE_TO_INDEX) == 24 and du.DATE_TO_INDEX["t12.2022.08.25"] == 23
     assert du.process_string("Hello, World! It's fine.") == "hello world it's fine"
+
+
+def test_wer_known_answers():
+    """utils.metrics.wer = total word edit distance / total reference words: the documented example of the HF `wer` metric the
+    reference's Whisper notebook loads (0.5), single substitutions / deletions / insertions, and the token-id variant with the
+    reference's -100 label padding dropped."""
+    from frankenstein_amd.utils.metrics import wer, token_error_rate, edit_distance
+    assert wer(["this is the reference", "there is another one"], ["this is the prediction", "there is an other sample"]) == 0.5
+    assert wer(["hello world"], ["hello duck"]) == 0.5
+    assert wer(["a b c d"], ["a b c d"]) == 0.0
+    assert wer(["a b c d"], ["a c d"]) == 0.25 and wer(["a b c d"], ["a b x c d"]) == 0.25
+    assert wer(["a b"], ["x y z w"]) == 2.0                      # more errors than reference words is allowed
+    assert edit_distance("kitten", "sitting") == 3 and edit_distance([], [1, 2]) == 2
+    assert token_error_rate([[1, 2, 3, -100, -100]], [[1, 2, 3]]) == 0.0
+    assert token_error_rate([[1, 2, 3, -100]], [[1, 3]]) == pytest.approx(1 / 3)
+    with pytest.raises(ValueError):
+        wer(["a"], ["a", "b"])
+    with pytest.raises(ValueError):
+        wer([""], ["a"])

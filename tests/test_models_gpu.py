@@ -136,6 +136,8 @@ def test_gpt_generate_greedy_matches_reference(golden, use_cache):
     pf = prefix[:1].cuda()
     out = g.generate(start.clone(), max_new_tokens=8, prefix=pf, top_k=1, use_cache=use_cache)
     assert out.dim() == 1 and out.cpu().tolist() == z["tokens"].tolist()
+    from frankenstein_amd.utils.metrics import token_error_rate
+    assert token_error_rate([z["tokens"].tolist()], [out.cpu().tolist()]) == 0.0      # the north star's "WER vs CPU ref" on decodes
     if use_cache:
         from frankenstein_amd import engine as E
         d, total = cfgo.n_embd, 5 + 4 + 8
