@@ -743,6 +743,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
       issue_a(sa == 0 ? 2 : sa - 1);
       const char* as = aslot(sa);
       const char* bs = bslot(sb);
+#ifndef FK_RING_PROBE_NOMMA
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         Frag<T> fa[MT], fb[2];
@@ -755,6 +756,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
       }
+#endif
       sa = sa == 2 ? 0 : sa + 1;
       sb ^= 1;
     }
