@@ -193,7 +193,7 @@ def main():
             roof = {"kernel": "fk_attn_bwd (attn_bwd_dq [+ delta] and attn_bwd_dkdv launches of one call)" if bwd else "fk_attn_fwd",
                     "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(fl / avg_s / MFMA_PEAK_BF16, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r01_pmc_traffic.json); algorithmic bytes 1.21e9",
+                    "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r01_pmc_traffic.json); algorithmic bytes 1.21e9 with every tensor counted once; the two deterministic kernels (dQ, dK/dV) each have to read Q, K, V, dO, so their compulsory traffic is 1.82e9",
                     "flops_per_launch": fl, "avg_launch_ms": round(avg_s * 1e3, 3)}
         out = {
             "metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "value": round(value, 1), "unit": "frames/s",
