@@ -19,6 +19,7 @@
 // P is recomputed from the saved log-sum-exp; delta = rowsum(dO * O) is computed by the dQ kernel (which runs first) and read by dK/dV.
 // fp32 variants (exact-fp32 MFMA) exist for the parity mode.
 #include "fk_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -562,19 +563,22 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   f32x16 dq[C::DT];
   zero_acc(dq);
 
-  for (int t = 0; t < ntiles; ++t) {
+  // the tile loop is unrolled by the ring depth so that the LDS slot is a compile-time constant: every fragment read then carries its slot
+  // offset in the instruction's immediate field instead of a per-read v_add_u32 (VALU issue is what bounds these kernels)
+  auto tile_step = [&](auto SL, int t) {
+    constexpr int SLOT = decltype(SL)::value;
     const int kb = t * BKV;
     if (t + 1 < ntiles) {
       if constexpr (DMA) {
-        kcur.next((const bf16_t*)Kp, p.k_rs, kb + BKV, p.Nk, kimg((t + 1) & 1), wave, lane);
-        vcur.next((const bf16_t*)Vp, p.v_rs, kb + BKV, p.Nk, vimg((t + 1) & 1), wave, lane);
+        kcur.next((const bf16_t*)Kp, p.k_rs, kb + BKV, p.Nk, kimg(SLOT ^ 1), wave, lane);
+        vcur.next((const bf16_t*)Vp, p.v_rs, kb + BKV, p.Nk, vimg(SLOT ^ 1), wave, lane);
       } else {
         sk.load(Kp, p.k_rs, kb + BKV, p.Nk, tid);
         sv.load(Vp, p.v_rs, kb + BKV, p.Nk, tid);
       }
     }
-    const char* kt = kimg(t & 1);
-    const char* vt = vimg(t & 1);
+    const char* kt = kimg(SLOT);
+    const char* vt = vimg(SLOT);
     const bool boundary = kb + BKV > full_vis_end;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -627,11 +631,15 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
     }
     if constexpr (!DMA) {
       if (t + 1 < ntiles) {
-        sk.store_img(kimg((t + 1) & 1), tid);
-        sv.store(vimg((t + 1) & 1), C::RSTRIDE, tid);
+        sk.store_img(kimg(SLOT ^ 1), tid);
+        sv.store(vimg(SLOT ^ 1), C::RSTRIDE, tid);
       }
     }
     __syncthreads();
+    };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile_step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile_step(std::integral_constant<int, 1>{}, t + 1);
   }
   T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
   if (p.rope_table && q_ok)
