@@ -741,21 +741,22 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   zero_acc(dk);
   zero_acc(dv);
 
-  for (int t = 0; t < ntiles; ++t) {
+  auto tile_step = [&](auto SL, int t) {             // unrolled by the ring depth: compile-time LDS slot (see attn_bwd_dq_kernel)
+    constexpr int SLOT = decltype(SL)::value;
     const int qb = qs + t * TQ;
     if (t + 1 < ntiles) {
       if constexpr (DMA) {
-        dma_tile_bf16_d64<TQ>((const bf16_t*)Qp, p.q_rs, qb + TQ, p.Nq, qimg((t + 1) & 1), wave, lane);
-        dma_tile_bf16_d64<TQ>((const bf16_t*)Gp, p.o_rs, qb + TQ, p.Nq, gimg((t + 1) & 1), wave, lane);
+        dma_tile_bf16_d64<TQ>((const bf16_t*)Qp, p.q_rs, qb + TQ, p.Nq, qimg(SLOT ^ 1), wave, lane);
+        dma_tile_bf16_d64<TQ>((const bf16_t*)Gp, p.o_rs, qb + TQ, p.Nq, gimg(SLOT ^ 1), wave, lane);
       } else {
         sq.load(Qp, p.q_rs, qb + TQ, p.Nq, tid);
         sg.load(Gp, p.o_rs, qb + TQ, p.Nq, tid);
       }
       load_stats(qb + TQ);
     }
-    const char* qt = qimg(t & 1);
-    const char* gt = gimg(t & 1);
-    const float* stl = stats + (t & 1) * 2 * TQ;
+    const char* qt = qimg(SLOT);
+    const char* gt = gimg(SLOT);
+    const float* stl = stats + SLOT * 2 * TQ;
     const float* std_ = stl + TQ;
     const bool boundary = (qb < full_vis_q) || (k0 + wave * 32 + 31 >= p.Nk);   // wave-uniform
     // phase 1: S = Q K^T and dP = dO V^T for both 32-row query sub-tiles (16 MFMAs back to back)
@@ -834,12 +835,16 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
       }
     if (t + 1 < ntiles) {
       if constexpr (!DMA) {
-        sq.store_img(qimg((t + 1) & 1), tid);
-        sg.store_img(gimg((t + 1) & 1), tid);
+        sq.store_img(qimg(SLOT ^ 1), tid);
+        sg.store_img(gimg(SLOT ^ 1), tid);
       }
-      store_stats((t + 1) & 1);
+      store_stats(SLOT ^ 1);
     }
     __syncthreads();
+    };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile_step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile_step(std::integral_constant<int, 1>{}, t + 1);
   }
   T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
   T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
