@@ -64,12 +64,16 @@ template <typename T> FK_DEV float sigmoid_f(float x) {
 }
 
 // Epilogue shared by the NT kernels: acc are C^T tiles (lane = output row m, registers = 4 consecutive n).
-template <typename T, typename TO, bool VEC_ONLY = false, int NI = 2, bool PRE_RES = false>
+// EPI < 0: every fused mode decided at run time (one code body); EPI = 0 plain / bias / residual, 1 SwiGLU forward, 2 SwiGLU backward,
+// 3 RoPE (+ bias): the same code with the other modes compiled out (the 256 x 256 kernel is instantiated per mode).
+template <typename T, typename TO, bool VEC_ONLY = false, int NI = 2, bool PRE_RES = false, int EPI = -1>
 FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mrow0, int ncol0, int lane, bool sync) {
   // acc = one wave's (32 NI) x 64 sub-tile whose top-left output element is (mrow0, ncol0); stg = that wave's 8 NI KiB of LDS
   const int li = lane & 31, lh = lane >> 5;
-  const T* bias = (const T*)p.bias;
-  const T* res = (const T*)p.res;
+  const T* bias = (EPI < 0 || EPI == 0 || EPI == 3) ? (const T*)p.bias : nullptr;
+  const T* res = (EPI < 0 || EPI == 0) ? (const T*)p.res : nullptr;
+  const int mode = EPI < 0 ? p.mode : (EPI == 1 ? 1 : (EPI == 2 ? 2 : 0));
+  const float* rope_table = (EPI < 0 || EPI == 3) ? p.rope_table : nullptr;
   TO* C = (TO*)p.C;
   if (VEC_ONLY || p.vec_epi) {
     // Vector epilogue: accumulators are C^T tiles (lane = output row m, registers = 4 consecutive n), staged as
@@ -126,11 +130,11 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     // RoPE: (cos, sin) pairs of token (m % T) of sample (m / T) for the 4 complex pairs of this lane's 8 columns
     const float* tb = nullptr;
     int tt = 0;
-    const bool do_rope = p.rope_table && nb < p.rope_cols && col_ok;
+    const bool do_rope = rope_table && nb < p.rope_cols && col_ok;
     if (do_rope) {
       tt = mb % p.rope_T;
       const int bb = mb / p.rope_T, dd = nb % p.rope_D;
-      tb = p.rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
+      tb = rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
     }
 #pragma unroll FK_EPI_UNROLL
     for (int ps = 0; ps < 4 * NI; ++ps) {
@@ -170,7 +174,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
             v[2 * j + 1] = __builtin_fmaf(re, cs[2 * j + 1], im * cs[2 * j]);
           }
         }
-        if (p.mode == 2) {
+        if (mode == 2) {
           // SwiGLU backward fused into the down-projection dgrad: v = dg[m, nb..nb+7]; h13 / dh13 use the interleaved hidden
           // layout (per 4 hidden units: 4 x h1 then 4 x h3), so the 8 units of this lane are 16 contiguous columns.
           if constexpr (sizeof(TO) == sizeof(T)) {
@@ -221,7 +225,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
             *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
           }
-          if (p.mode == 1) {
+          if (mode == 1) {
             // SwiGLU forward fused into the up-projection: the 8 columns are (h1[4], h3[4]) of 4 hidden units
             if constexpr (sizeof(TO) == sizeof(T)) {
               T* gp = (T*)p.aux + (int64_t)m * p.ldaux + (nb >> 1);
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
 // just computed (4 waves each).  LDS = 96 + 64 KiB.
 constexpr int R2_A = 256 * ROW_BYTES, R2_LDS = 5 * R2_A;
 
-template <typename TO>
+template <typename TO, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
   using T = bf16_t;
   constexpr int BM_ = 256, BN_ = 256, APW = 4, BPW = 4, WM = 128, MT = 4;
@@ -765,18 +769,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
-      nt_epilogue<T, TO, true, 1>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
+      nt_epilogue<T, TO, true, 1, false, EPI>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
     }
   }
 }
 
-template <typename TO>
-static void launch_ring2(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
+template <typename TO, int EPI>
+static void launch_ring2_epi(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
   const int64_t nt = fk_cdiv(M, 256) * fk_cdiv(N, 256);
-  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring2_kernel<TO>),
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring2_kernel<TO, EPI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS) == hipSuccess);
   (void)once;
-  hipLaunchKernelGGL((gemm_nt_ring2_kernel<TO>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R2_LDS, s, p);
+  hipLaunchKernelGGL((gemm_nt_ring2_kernel<TO, EPI>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R2_LDS, s, p);
+}
+template <typename TO>
+static void launch_ring2(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
+  static const bool generic = getenv("FK_NT_RING2_GENERIC") != nullptr;    // tuning knob: one epilogue body for every mode
+  if (generic) launch_ring2_epi<TO, -1>(p, M, N, s);
+  else if (p.mode == 1) launch_ring2_epi<TO, 1>(p, M, N, s);
+  else if (p.mode == 2) launch_ring2_epi<TO, 2>(p, M, N, s);
+  else if (p.rope_table) launch_ring2_epi<TO, 3>(p, M, N, s);
+  else launch_ring2_epi<TO, 0>(p, M, N, s);
 }
 
 template <typename TO, int BN_, int RB, int NS>
