@@ -552,7 +552,7 @@ template <int BN_, int RB, int NS> struct Ring {
 template <int RB> FK_DEV int ring_swz(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 template <int RB> FK_DEV int ring_off(int row, int chunk) { return row * RB + ((chunk ^ ring_swz<RB>(row)) << 4); }
 
-template <typename TO, int BN_, int RB, int NS>
+template <typename TO, int BN_, int RB, int NS, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
   using T = bf16_t;
   using R = Ring<BN_, RB, NS>;
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
-      if (BN_ == 128 && p.res) nt_epilogue<T, TO, true, 1, true>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
-      else nt_epilogue<T, TO, true, 1, false>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
+      if (EPI == 0 && BN_ == 128 && p.res) nt_epilogue<T, TO, true, 1, true, EPI>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
+      else nt_epilogue<T, TO, true, 1, false, EPI>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
     }
   }
 }
@@ -792,14 +792,21 @@ static void launch_ring2(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
   else launch_ring2_epi<TO, 0>(p, M, N, s);
 }
 
-template <typename TO, int BN_, int RB, int NS>
-static void launch_ring(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
+template <typename TO, int BN_, int RB, int NS, int EPI>
+static void launch_ring_epi(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
   using R = Ring<BN_, RB, NS>;
   const int64_t nt = fk_cdiv(M, R::BM_) * (N / BN_);
-  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<TO, BN_, RB, NS>),
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<TO, BN_, RB, NS, EPI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS) == hipSuccess);
   (void)once;
-  hipLaunchKernelGGL((gemm_nt_ring_kernel<TO, BN_, RB, NS>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R::LDS, s, p);
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<TO, BN_, RB, NS, EPI>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R::LDS, s, p);
+}
+template <typename TO, int BN_, int RB, int NS>
+static void launch_ring(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {   // one instantiation per fused epilogue mode
+  if (p.mode == 1) launch_ring_epi<TO, BN_, RB, NS, 1>(p, M, N, s);
+  else if (p.mode == 2) launch_ring_epi<TO, BN_, RB, NS, 2>(p, M, N, s);
+  else if (p.rope_table) launch_ring_epi<TO, BN_, RB, NS, 3>(p, M, N, s);
+  else launch_ring_epi<TO, BN_, RB, NS, 0>(p, M, N, s);
 }
 
 // ------------------------------------------------------------------------------------------------ TN
