@@ -106,6 +106,22 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
         rq0 = fetch(0); rq1 = fetch(1); rq2 = fetch(2); rq3 = fetch(3);
       }
     }
+    // ... and for the (cos, sin) rows of the fused RoPE in the kernels instantiated for it (2 x 16 B per pass from the L2-resident table)
+    constexpr bool PROPE = (EPI == 3) && (NI == 1);
+    f32x4 ta0 = {}, ta1 = {}, ta2 = {}, ta3 = {}, tc0 = {}, tc1 = {}, tc2 = {}, tc3 = {};
+    if constexpr (PROPE) {
+      if (rope_table && nb < p.rope_cols && col_ok) {
+        int tt = mb % p.rope_T;
+        const float* tp = rope_table + (int64_t)(mb / p.rope_T) * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + (nb % p.rope_D) / 2) * 2;
+        auto fetch = [&](int ps, f32x4& lo, f32x4& hi) {
+          if (mb + 8 * ps < p.M) { lo = *reinterpret_cast<const f32x4*>(tp); hi = *reinterpret_cast<const f32x4*>(tp + 4); }
+          tt += 8;
+          tp += 8 * p.rope_D;
+          while (tt >= p.rope_T) { tt -= p.rope_T; tp += p.rope_bs - (int64_t)p.rope_T * p.rope_D; }
+        };
+        fetch(0, ta0, tc0); fetch(1, ta1, tc1); fetch(2, ta2, tc2); fetch(3, ta3, tc3);
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -131,7 +147,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     const float* tb = nullptr;
     int tt = 0;
     const bool do_rope = rope_table && nb < p.rope_cols && col_ok;
-    if (do_rope) {
+    if (do_rope && !PROPE) {
       tt = mb % p.rope_T;
       const int bb = mb / p.rope_T, dd = nb % p.rope_D;
       tb = rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
@@ -163,7 +179,9 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
           }
         }
         if (do_rope) {
-          const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 4);
+          f32x4 t0, t1;
+          if constexpr (PROPE) { t0 = ta0; t1 = tc0; }
+          else { t0 = *reinterpret_cast<const f32x4*>(tb); t1 = *reinterpret_cast<const f32x4*>(tb + 4); }
           const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -254,9 +272,13 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
         }
       }
       if (do_rope) {
-        tt += 8;
-        tb += 8 * p.rope_D;
-        while (tt >= p.rope_T) { tt -= p.rope_T; tb += p.rope_bs - (int64_t)p.rope_T * p.rope_D; }
+        if constexpr (PROPE) {
+          ta0 = ta1; ta1 = ta2; ta2 = ta3; tc0 = tc1; tc1 = tc2; tc2 = tc3;     // next pass's prefetched pair
+        } else {
+          tt += 8;
+          tb += 8 * p.rope_D;
+          while (tt >= p.rope_T) { tt -= p.rope_T; tb += p.rope_bs - (int64_t)p.rope_T * p.rope_D; }
+        }
       }
     }
     return;
