@@ -122,6 +122,23 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
         fetch(0, ta0, tc0); fetch(1, ta1, tc1); fetch(2, ta2, tc2); fetch(3, ta3, tc3);
       }
     }
+    // ... and for the saved h13 rows of the fused SwiGLU backward (2 x 16 B per pass); that instantiation unrolls the sweep so the
+    // prefetch registers are indexed statically
+    constexpr bool PAUX = (EPI == 2) && (NI == 1) && sizeof(T) == 2 && sizeof(TO) == 2;
+    constexpr int SWEEP_UNROLL = PAUX ? 4 : FK_EPI_UNROLL;
+    bf16x8 hq0[4], hq1[4];
+    if constexpr (PAUX) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        hq0[ps] = bf16x8{};
+        hq1[ps] = bf16x8{};
+        if (mb + 8 * ps < p.M && col_ok) {
+          const T* hp = (const T*)p.aux + (int64_t)(mb + 8 * ps) * p.ldaux + 2 * nb;
+          hq0[ps] = *reinterpret_cast<const bf16x8*>(hp);
+          hq1[ps] = *reinterpret_cast<const bf16x8*>(hp + 8);
+        }
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -152,7 +169,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
       const int bb = mb / p.rope_T, dd = nb % p.rope_D;
       tb = rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
     }
-#pragma unroll FK_EPI_UNROLL
+#pragma unroll SWEEP_UNROLL
     for (int ps = 0; ps < 4 * NI; ++ps) {
       const int row = ps * 8 + r0, m = mrow0 + row;
       f32x4 a = *reinterpret_cast<const f32x4*>(stg + eoff(row, col));
@@ -199,7 +216,10 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
             const T* hp = (const T*)p.aux + (int64_t)m * p.ldaux + 2 * nb;
             T* dp = (T*)p.C + (int64_t)m * p.ldc + 2 * nb;
             float hv[16], ov[16];
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (PAUX) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { hv[e] = (float)hq0[ps & 3][e]; hv[8 + e] = (float)hq1[ps & 3][e]; }
+            } else if constexpr (sizeof(T) == 2) {
               bf16x8 h0 = *reinterpret_cast<const bf16x8*>(hp), h1 = *reinterpret_cast<const bf16x8*>(hp + 8);
 #pragma unroll
               for (int e = 0; e < 8; ++e) { hv[e] = (float)h0[e]; hv[8 + e] = (float)h1[e]; }
