@@ -125,7 +125,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     // ... and for the saved h13 rows of the fused SwiGLU backward (2 x 16 B per pass); that instantiation unrolls the sweep so the
     // prefetch registers are indexed statically
     constexpr bool PAUX = (EPI == 2) && (NI == 1) && sizeof(T) == 2 && sizeof(TO) == 2;
-    constexpr int SWEEP_UNROLL = PAUX ? 4 : FK_EPI_UNROLL;
+    constexpr int SWEEP_UNROLL = (PAUX || EPI == 1) ? 4 : FK_EPI_UNROLL;
     bf16x8 hq0[4], hq1[4];
     if constexpr (PAUX) {
 #pragma unroll
