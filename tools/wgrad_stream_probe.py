@@ -13,6 +13,11 @@ cfg = bf.Config(encoder=enc, n_output_tokens=9, output_dim=70, dim=320, n_layers
 g = torch.Generator(device="cuda").manual_seed(5)
 x = torch.randn(3, 475, 256, device="cuda", generator=g)
 y = torch.randn(3, 9, 70, device="cuda", generator=g)
+if os.environ.get("PROBE_CFG2"):                     # the benchmark's dimensions at B = 2 (ring-buffered GEMMs, large-tile TN)
+    enc = bf.MAEConfig(window_size=600, n_electrodes=256, patch_size=25, dim=384, n_layers=2, head_dim=64, hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=64, dim=384, n_layers=1, head_dim=64, hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    x = torch.randn(2, 600, 256, device="cuda", generator=g)
+    y = torch.randn(2, 32, 64, device="cuda", generator=g)
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 runs = []
 for rep in range(3):
