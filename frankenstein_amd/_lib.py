@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("FRANKEN_HIP_LIB") or Path(__file__).resolve().pa
 FK_F32, FK_BF16 = 0, 1
 MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL, MASK_PREFIX, MASK_KEYPAD = 0, 1, 2, 3, 4
 NORM_LAYER, NORM_RMS = 0, 1
+ATTN_Q_PRESCALED = 1
 
 _p, _i64, _int, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_size_t
 
@@ -24,15 +25,15 @@ SIGNATURES = {
     "fk_version": (_int, []),
     "fk_last_error": (C.c_char_p, []),
     "fk_gemm_nt": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _int, _int, _p]),
-    "fk_gemm_nt_rope": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),
+    "fk_gemm_nt_rope": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_nt_swiglu": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_nt_dswiglu": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "fk_gemm_tn": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _int, _p, _sz, _p]),
     "fk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "fk_colsum": (_int, [_p, _i64, _p, _i64, _i64, _int, _int, _p, _sz, _p]),
-    "fk_attn_fwd": (_int, [_p, _p, _p, _p, _p] + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _int, _p]),
-    "fk_attn_bwd": (_int, [_p] * 10 + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _p, _i64, _i64, _int, _p]),
+    "fk_attn_fwd": (_int, [_p, _p, _p, _p, _p] + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _int, _int, _p]),
+    "fk_attn_bwd": (_int, [_p] * 10 + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _p, _i64, _i64, _int, _int, _p]),
     "fk_norm_fwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _int, _int, _p]),
     "fk_norm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "fk_norm_bwd": (_int, [_p] * 9 + [_i64, _i64, _int, _int, _int, _p, _sz, _p]),

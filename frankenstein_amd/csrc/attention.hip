@@ -41,6 +41,7 @@ struct AttnArgs {
   // FK_MASK_PREFIX: visible(q, k) = k < limits[b, q]  <=>  q >= qfirst[b, k]  (both non-decreasing; built by fk_prefix_mask
   // from sorted per-token block ids: the per-sample sub-mask of MAE, models/brainformer.py:392-413)
   const int* limits; const int* qfirst;
+  int flags;          // FK_ATTN_Q_PRESCALED
 };
 
 template <typename T, int D> struct AT {
@@ -855,6 +856,511 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   store_rows_T<T, D>(dVp, p.v_rs, krow, k_ok, dv, 1.0f, lh);
 }
 
+
+// ================================================================================================= pre-scaled Q (bf16, D = 64)
+// FK_ATTN_Q_PRESCALED: the projection epilogue has already multiplied Q by scale * log2(e) (fk_gemm_nt_rope's second table), so
+// S2 = Q' K^T is the score in the exp2 domain.  VALU issue, not the matrix pipe, bounds these kernels (SQ counters: 13 VALU
+// instructions per MFMA in the forward, 7.5 in the backward, profiles/r01_pmc_sq_attention.txt), so everything per score that is not
+// the exponential itself is moved into the matrix instruction: the row constant of each product is its INITIAL ACCUMULATOR.
+//   forward : S' = Q'K^T - m_ref (accumulator preset to -m_ref),  P = exp2(S');  m_ref is a per-row reference, not the running
+//             maximum: online softmax is exact for ANY reference, the maximum only keeps exp2 in range.  The hot path therefore
+//             computes no maximum at all; a tile whose half-row sum of P exceeds PS_REDO (or is not finite), or a row that has no
+//             reference yet, takes the exact path (true tile maximum, rescale of O and l, new reference) — wave-uniform and rare:
+//             the first visible tile of a row, and afterwards only if a score outgrows the reference by more than ~40 (log2 units).
+//             bf16 has fp32's exponent range, so P up to 2^40 keeps the same relative precision as P <= 1.
+//   backward: S' = Q'K^T - LSE*log2(e) and dP' = dO V^T - delta start from the row constants, P = exp2(S'), dS = P * dP'.
+constexpr float PS_REDO = 1.0e12f;
+constexpr float LN2 = 0.6931471805599453f;
+
+FK_DEV f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// every wave's LDS-DMA of the next tile has landed and every wave is done with the current one
+FK_DEV void dma_wait_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64, BQ = NW * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KIMG = BKV * 128, VIMG = BKV * 128, NSLOT = 3;
+  auto kimg = [&](int i) -> char* { return smem + i * KIMG; };
+  auto vimg = [&](int i) -> char* { return smem + NSLOT * KIMG + i * VIMG; };
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (p.Nq + BQ - 1) / BQ;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nqb), b = bh / p.H, hd = bh % p.H, q0 = (nqb - 1 - (int)(L % nqb)) * BQ;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const int qrow = q0 + wave * 32 + li;
+  const bool q_ok = qrow < p.Nq;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const int my_lim = ((prefix || keypad) && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;
+
+  Frag<T> qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (q_ok) frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+    else frag_zero<T>(qf[s]);
+  }
+  const int q_last = min(q0 + BQ, p.Nq) - 1;
+  const int kv_end = keypad ? p.Nk : kv_limit(p, b, q_last);
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+  const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
+  const int full_vis_end = kv_limit(p, b, wave_q_first);
+
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): from here on vmcnt counts only LDS-DMA instructions (see attn_fwd_kernel)
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt)
+    if (pt < ntiles) {
+      dma_tile_bf16_d64<BKV, NW>(Kp, p.k_rs, pt * BKV, p.Nk, kimg(pt), wave, lane);
+      dma_tile_bf16_d64<BKV, NW>(Vp, p.v_rs, pt * BKV, p.Nk, vimg(pt), wave, lane);
+    }
+  float m = -INFINITY, l = 0.0f;        // m: this row's reference (exp2 domain); -inf = none yet
+  f32x16 o[2];
+  zero_acc(o);
+
+  // Work proceeds in 32-key sub-tiles j = 2 t + u (nothing couples the two halves of a staged tile once there is no tile-wide maximum);
+  // the ring bookkeeping runs when a tile is entered.
+  int slot = -1, entered = -1;
+  auto enter_tile = [&](int t) {
+    if (t == entered) return;
+    entered = t;
+    slot = slot == 2 ? 0 : slot + 1;                // t % 3
+    // retire tile t's DMA (oldest of this wave) but leave tile t+1's in flight across the barrier; the barrier also guarantees every
+    // wave is done reading slot (t+2)%3 (= tile t-1), which is refilled right after it.
+    if (t + 1 < ntiles) {
+      if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    if (t + 1 >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < ntiles) {
+      const int ns = slot >= 1 ? slot - 1 : 2;     // (t + 2) % 3
+      dma_tile_bf16_d64<BKV, NW>(Kp, p.k_rs, (t + 2) * BKV, p.Nk, kimg(ns), wave, lane);
+      dma_tile_bf16_d64<BKV, NW>(Vp, p.v_rs, (t + 2) * BKV, p.Nk, vimg(ns), wave, lane);
+    }
+  };
+  // S2 = Q' K^T of sub-tile j (accumulator starts from literal zero), masked on boundary sub-tiles
+  auto scores = [&](int j, f32x16& sc) {
+    const char* kt = kimg(slot) + (j & 1) * 4096;   // 32 image rows further on (the chunk swizzle has period 16 rows)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Frag<T> kf;
+      img_row<T, D>(kf, kt, li, s, lh);
+      mma32<T>(sc, kf, qf[s]);
+    }
+    if (32 * j + 32 > full_vis_end) {               // wave-uniform: boundary sub-tile -> per-element predicate
+      const int qpos = qrow + p.q_off;
+      // opaque to the optimiser: otherwise the 16 key indices are shared between the call sites and hoisted out of the branch into the
+      // hot paths, where they cost 32 live registers (60 spills at 4 waves per SIMD)
+      int kbase = 32 * j + 4 * lh;
+      asm volatile("" : "+v"(kbase));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))))) sc[r] = -INFINITY;
+      }
+    }
+  };
+  // O^T += V^T P^T for sub-tile j
+  auto pv = [&](int j, const f32x16& sc) {
+    const char* vt = vimg(slot) + (j & 1) * 4096;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> pf;
+      frag_from_acc<T>(pf, sc, s);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag<T> vf;
+        img_tr<T, D>(vf, vt, 0, s, 32 * dt, lane);
+        mma32<T>(o[dt], vf, pf);
+      }
+    }
+  };
+  // classic online softmax with a running maximum (exact deferred rescale): first sub-tiles of a row, and the fallback
+  auto classic = [&](int j) {
+    f32x16 sc;
+    scores(j, sc);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (__builtin_amdgcn_ballot_w64(tmax > m) != 0) {
+      const float m_new = fmaxf(m, tmax);
+      const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m - m_new);
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float mr = (m == -INFINITY) ? 0.0f : m;
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(sc[r] - mr);
+      sc[r] = e;
+      rs += e;
+    }
+    l += rs;
+    pv(j, sc);
+  };
+  // reference 0: P = exp2(S2), nothing else per score.  Returns false (sub-tile NOT consumed) when a half-row sum leaves the safe range.
+  auto zref = [&](int j) -> bool {
+    f32x16 sc;
+    scores(j, sc);
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(sc[r]);
+      sc[r] = e;
+      rs += e;
+    }
+    if (__builtin_amdgcn_ballot_w64(!(rs <= PS_REDO)) != 0) return false;
+    l += rs;
+    pv(j, sc);
+    return true;
+  };
+
+  const int J = 2 * ntiles;
+  int j = 0;
+  bool win = false;
+  // 1. classic until every row of the wave has a maximum inside the window in which reference 0 can neither overflow nor lose the row
+  for (; j < J && !win; ++j) {
+    enter_tile(j >> 1);
+    classic(j);
+    win = __builtin_amdgcn_ballot_w64(!(m >= -64.0f && m <= 32.0f)) == 0;
+  }
+  if (win) {
+    // 2. re-reference to 0 and run the lean loop
+    const float a = __builtin_amdgcn_exp2f(m);
+    m = 0.0f;
+    l *= a;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= a;
+    for (; j < J; ++j) {
+      enter_tile(j >> 1);
+      if (!zref(j)) break;
+    }
+  }
+  // 3. whatever is left after a score outgrew the window (reference 0 stays a valid running reference for the classic loop)
+  for (; j < J; ++j) {
+    enter_tile(j >> 1);
+    classic(j);
+  }
+
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;   // fully masked row -> 0 (torch >= 2.1 CPU semantics)
+  T* Op = (T*)p.Out + (int64_t)b * p.o_bs + hd * D;
+  store_rows_T<T, D>(Op, p.o_rs, qrow, q_ok, o, inv, lh);
+  if (q_ok && lh == 0 && p.LSE)
+    p.LSE[((int64_t)b * p.H + hd) * p.Nq + qrow] = lt > 0.0f ? m * LN2 + logf(lt) : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------- dQ (pre-scaled Q)
+__global__ __launch_bounds__(NT) void attn_bwd_dq_ps_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = BKV * 128;
+  auto kimg = [&](int i) -> char* { return smem + i * IMG; };
+  auto vimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (p.Nq + BQ - 1) / BQ;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nqb), b = bh / p.H, hd = bh % p.H, q0 = (nqb - 1 - (int)(L % nqb)) * BQ;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const int qrow = q0 + wave * 32 + li;
+  const bool q_ok = qrow < p.Nq;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const int my_lim = ((prefix || keypad) && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;
+
+  Frag<T> qf[4], gf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (q_ok) {
+      frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+      frag_load_contig<T>(gf[s], Gp + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
+    } else {
+      frag_zero<T>(qf[s]);
+      frag_zero<T>(gf[s]);
+    }
+  }
+  const int64_t stat = ((int64_t)b * p.H + hd) * p.Nq + qrow;
+  const float lse2 = q_ok ? p.LSE[stat] * LOG2E : INFINITY;   // +inf -> P = 0 for padded / fully masked rows
+  float dl = 0.0f;                                             // delta = rowsum(dO * O), published for the dK/dV kernel
+  {
+    const T* Op = (const T*)p.O + (int64_t)b * p.o_bs + hd * D;
+    float part = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (q_ok) {
+        Frag<T> of;
+        frag_load_contig<T>(of, Op + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += to_f32<T>(of.v[e]) * to_f32<T>(gf[s].v[e]);
+      }
+    }
+    dl = part + __shfl_xor(part, 32, 64);
+    if (q_ok && lh == 0) p.delta[stat] = dl;
+  }
+  f32x16 cl, cd;       // the row constants as initial accumulators: S' = Q'K^T - lse2, dP' = dO V^T - delta
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { cl[r] = -lse2; cd[r] = -dl; }
+
+  const int q_last = min(q0 + BQ, p.Nq) - 1;
+  const int kv_end = keypad ? p.Nk : kv_limit(p, b, q_last);
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+  const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
+  const int full_vis_end = kv_limit(p, b, wave_q_first);
+
+  DmaCursor<BKV> kcur, vcur;
+  if (ntiles > 0) {
+    kcur.init(Kp, p.k_rs, 0, wave, lane);
+    vcur.init(Vp, p.v_rs, 0, wave, lane);
+    kcur.next(Kp, p.k_rs, 0, p.Nk, kimg(0), wave, lane);
+    vcur.next(Vp, p.v_rs, 0, p.Nk, vimg(0), wave, lane);
+  }
+  dma_wait_barrier();
+  f32x16 dq[2];
+  zero_acc(dq);
+
+  auto tile_step = [&](auto SL, int t) {
+    constexpr int SLOT = decltype(SL)::value;
+    const int kb = t * BKV;
+    if (t + 1 < ntiles) {
+      kcur.next(Kp, p.k_rs, kb + BKV, p.Nk, kimg(SLOT ^ 1), wave, lane);
+      vcur.next(Vp, p.v_rs, kb + BKV, p.Nk, vimg(SLOT ^ 1), wave, lane);
+    }
+    const char* kt = kimg(SLOT);
+    const char* vt = vimg(SLOT);
+    const bool boundary = kb + BKV > full_vis_end;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x16 sc, dp;
+      {
+        Frag<T> kf, vf;
+        img_row<T, D>(kf, kt, 32 * u + li, 0, lh);
+        img_row<T, D>(vf, vt, 32 * u + li, 0, lh);
+        sc = mfma_bf16(kf.v, qf[0].v, cl);
+        dp = mfma_bf16(vf.v, gf[0].v, cd);
+      }
+#pragma unroll
+      for (int s = 1; s < 4; ++s) {
+        Frag<T> kf, vf;
+        img_row<T, D>(kf, kt, 32 * u + li, s, lh);
+        img_row<T, D>(vf, vt, 32 * u + li, s, lh);
+        mma32<T>(sc, kf, qf[s]);
+        mma32<T>(dp, vf, gf[s]);
+      }
+      if (!boundary) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]) * dp[r];    // dS^T (softmax scale folded into the final store)
+      } else {
+        const int qpos = qrow + p.q_off;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = __builtin_amdgcn_exp2f(sc[r]);
+          const int key = kb + 32 * u + acc_row(r, lh);
+          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))))) pv = 0.0f;
+          sc[r] = pv * dp[r];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag<T> df;
+        frag_from_acc<T>(df, sc, s);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          Frag<T> ktf;
+          img_tr<T, D>(ktf, kt, 32 * u, s, 32 * dt, lane);
+          mma32<T>(dq[dt], ktf, df);
+        }
+      }
+    }
+    dma_wait_barrier();
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile_step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile_step(std::integral_constant<int, 1>{}, t + 1);
+  }
+  T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
+  if (p.rope_table && q_ok)
+    store_rows_T_rope<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + qrow) * D);
+  else
+    store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
+}
+
+// ------------------------------------------------------------------------------------------------- dK, dV (pre-scaled Q)
+__global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64, TQ = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = TQ * 128;
+  auto qimg = [&](int i) -> char* { return smem + i * IMG; };
+  auto gimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
+  float* stats = reinterpret_cast<float*>(smem + 4 * IMG);   // [2 buffers][2 (-lse2, -delta)][TQ]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkb = (p.Nk + 127) / 128;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nkb), b = bh / p.H, hd = bh % p.H, k0 = (int)(L % nkb) * 128;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const int krow = k0 + wave * 32 + li;
+  const bool k_ok = krow < p.Nk;
+  const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const int my_qf = ((prefix || keypad) && k_ok) ? p.qfirst[(int64_t)b * p.Nk + krow] : 0;
+
+  Frag<T> kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (k_ok) {
+      frag_load_contig<T>(kf[s], Kp + (int64_t)krow * p.k_rs + 16 * s + 8 * lh);
+      frag_load_contig<T>(vf[s], Vp + (int64_t)krow * p.v_rs + 16 * s + 8 * lh);
+    } else {
+      frag_zero<T>(kf[s]);
+      frag_zero<T>(vf[s]);
+    }
+  }
+  const int qs = keypad ? 0 : (q_first(p, b, k0) / TQ) * TQ;
+  const int ntiles = qs < p.Nq ? (p.Nq - qs + TQ - 1) / TQ : 0;
+  const int full_vis_q = q_first(p, b, min(k0 + wave * 32 + 31, p.Nk - 1));
+  const int64_t stat0 = ((int64_t)b * p.H + hd) * p.Nq;
+
+  float st_l = 0.0f, st_d = 0.0f;
+  bool st_ok = false;
+  auto load_stats = [&](int qb) {      // raw loads only (see attn_bwd_dkdv_kernel)
+    if (tid < TQ) {
+      const int q = qb + tid;
+      st_ok = q < p.Nq;
+      if (st_ok) {
+        st_l = p.LSE[stat0 + q];
+        st_d = p.delta[stat0 + q];
+      }
+    }
+  };
+  auto store_stats = [&](int buf) {
+    if (tid < TQ) {
+      stats[buf * 2 * TQ + tid] = st_ok ? -(st_l * LOG2E) : -INFINITY;
+      stats[buf * 2 * TQ + TQ + tid] = st_ok ? -st_d : 0.0f;
+    }
+  };
+  if (ntiles > 0) {
+    dma_tile_bf16_d64<TQ>(Qp, p.q_rs, qs, p.Nq, qimg(0), wave, lane);
+    dma_tile_bf16_d64<TQ>(Gp, p.o_rs, qs, p.Nq, gimg(0), wave, lane);
+    load_stats(qs);
+    store_stats(0);
+  }
+  dma_wait_barrier();
+  f32x16 dk[2], dv[2];
+  zero_acc(dk);
+  zero_acc(dv);
+
+  auto tile_step = [&](auto SL, int t) {
+    constexpr int SLOT = decltype(SL)::value;
+    const int qb = qs + t * TQ;
+    if (t + 1 < ntiles) {
+      dma_tile_bf16_d64<TQ>(Qp, p.q_rs, qb + TQ, p.Nq, qimg(SLOT ^ 1), wave, lane);
+      dma_tile_bf16_d64<TQ>(Gp, p.o_rs, qb + TQ, p.Nq, gimg(SLOT ^ 1), wave, lane);
+      load_stats(qb + TQ);
+    }
+    const char* qt = qimg(SLOT);
+    const char* gt = gimg(SLOT);
+    const float* stl = stats + SLOT * 2 * TQ;
+    const float* std_ = stl + TQ;
+    const bool boundary = (qb < full_vis_q) || (k0 + wave * 32 + 31 >= p.Nk);   // wave-uniform
+    // phase 1: S' = Q'K^T - lse2 and dP' = dO V^T - delta: the accumulators start from the staged row constants
+    f32x16 sc[2], dp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + 32 * u + 8 * g + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(std_ + 32 * u + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[u][4 * g + j] = l4[j]; dp[u][4 * g + j] = d4[j]; }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> qf, gf;
+        img_row<T, D>(qf, qt, 32 * u + li, s, lh);
+        img_row<T, D>(gf, gt, 32 * u + li, s, lh);
+        mma32<T>(sc[u], qf, kf[s]);   // S'[q][key]
+        mma32<T>(dp[u], gf, vf[s]);   // dP'[q][key]
+      }
+    }
+    // phase 2: P = exp2(S'), dS = P dP'
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!boundary) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(sc[u][r]);
+          sc[u][r] = pv;
+          dp[u][r] *= pv;
+        }
+      } else {
+        const int kpos = krow + p.k_off;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = __builtin_amdgcn_exp2f(sc[u][r]);
+          const int q = qb + 32 * u + acc_row(r, lh);
+          if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))))) pv = 0.0f;
+          sc[u][r] = pv;
+          dp[u][r] *= pv;
+        }
+      }
+    }
+    // phase 3: dV^T += dO^T P, dK^T += Q'^T dS
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag<T> pf, df;
+        frag_from_acc<T>(pf, sc[u], s);
+        frag_from_acc<T>(df, dp[u], s);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          Frag<T> gtf, qtf;
+          img_tr<T, D>(gtf, gt, 32 * u, s, 32 * dt, lane);
+          img_tr<T, D>(qtf, qt, 32 * u, s, 32 * dt, lane);
+          mma32<T>(dv[dt], gtf, pf);
+          mma32<T>(dk[dt], qtf, df);
+        }
+      }
+    if (t + 1 < ntiles) store_stats(SLOT ^ 1);
+    dma_wait_barrier();
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile_step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile_step(std::integral_constant<int, 1>{}, t + 1);
+  }
+  // dK = scale * dS^T Q = ln(2) * dS^T Q'   (Q' = scale * log2(e) * Q)
+  T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
+  T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
+  if (p.rope_table && k_ok)
+    store_rows_T_rope<T, D>(dKp, p.k_rs, krow, k_ok, dk, LN2, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + krow) * D);
+  else
+    store_rows_T<T, D>(dKp, p.k_rs, krow, k_ok, dk, LN2, lh);
+  store_rows_T<T, D>(dVp, p.v_rs, krow, k_ok, dv, 1.0f, lh);
+}
+
 // ------------------------------------------------------------------------------------------------- host
 template <typename T, int D> size_t fwd_lds() {
   return Img<T, D>::SWZ ? (size_t)3 * 2 * BKV * 128 : (size_t)2 * BKV * (AT<T, D>::RSTRIDE + AT<T, D>::VSTRIDE);
@@ -868,6 +1374,15 @@ template <typename K> void allow_lds(K kernel, size_t bytes) {
 
 template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
   constexpr int NW = Img<T, D>::SWZ ? 8 : 4;
+  if constexpr (Img<T, D>::SWZ) {
+    if (a.flags & FK_ATTN_Q_PRESCALED) {
+      dim3 grid((unsigned)(((a.Nq + NW * 32 - 1) / (NW * 32)) * a.H * a.B));
+      const size_t lds = fwd_lds<T, D>();
+      allow_lds(attn_fwd_ps_kernel<NW>, lds);
+      hipLaunchKernelGGL((attn_fwd_ps_kernel<NW>), grid, dim3(NW * 64), lds, s, a);
+      return 0;
+    }
+  }
   dim3 grid((unsigned)(((a.Nq + NW * 32 - 1) / (NW * 32)) * a.H * a.B));
   const size_t lds = fwd_lds<T, D>();
   allow_lds(attn_fwd_kernel<T, D, NW>, lds);
@@ -881,6 +1396,15 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
   allow_lds(attn_bwd_dkdv_kernel<T, D>, lds_kv);
   allow_lds(attn_bwd_dq_kernel<T, D>, lds_q);
   dim3 gq((unsigned)(((a.Nq + BQ - 1) / BQ) * a.H * a.B));
+  if constexpr (Img<T, D>::SWZ) {
+    if (a.flags & FK_ATTN_Q_PRESCALED) {
+      allow_lds(attn_bwd_dkdv_ps_kernel, lds_kv);
+      allow_lds(attn_bwd_dq_ps_kernel, lds_q);
+      hipLaunchKernelGGL(attn_bwd_dq_ps_kernel, gq, dim3(NT), lds_q, s, a);
+      hipLaunchKernelGGL(attn_bwd_dkdv_ps_kernel, gk, dim3(NT), lds_kv, s, a);
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), gq, dim3(NT), lds_q, s, a);
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D>), gk, dim3(NT), lds_kv, s, a);
   return 0;
@@ -935,10 +1459,12 @@ extern "C" {
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
                 int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
                 int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
-                const int32_t* limits, const int32_t* qfirst, float scale, int dtype, void* stream) {
+                const int32_t* limits, const int32_t* qfirst, float scale, int flags, int dtype, void* stream) {
   const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
   int rc = check_common("fk_attn_fwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
   if (rc) return rc;
+  FK_CHECK_ARG((flags & ~FK_ATTN_Q_PRESCALED) == 0 && (!(flags & FK_ATTN_Q_PRESCALED) || (dtype == FK_BF16 && D == 64)),
+               "fk_attn_fwd: bad flags %d (FK_ATTN_Q_PRESCALED needs bf16, D = 64)", flags);
   FK_CHECK_ARG(Q && K && V && O, "fk_attn_fwd: null pointer");
   FK_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0, "fk_attn_fwd: pointers must be 16-byte aligned");
   AttnArgs a{};
@@ -947,7 +1473,7 @@ int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
   a.B = (int)B; a.H = (int)H; a.Nq = (int)Nq; a.Nk = (int)Nk;
   a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
   FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_fwd: prefix / key-padding masks need both tables");
-  a.limits = limits; a.qfirst = qfirst;
+  a.limits = limits; a.qfirst = qfirst; a.flags = flags;
   FK_ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_fwd");
   return FK_OK;
@@ -957,11 +1483,13 @@ int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
                 void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                 int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
                 int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
-                const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int dtype,
-                void* stream) {
+                const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int flags,
+                int dtype, void* stream) {
   const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
   int rc = check_common("fk_attn_bwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
   if (rc) return rc;
+  FK_CHECK_ARG((flags & ~FK_ATTN_Q_PRESCALED) == 0 && (!(flags & FK_ATTN_Q_PRESCALED) || (dtype == FK_BF16 && D == 64)),
+               "fk_attn_bwd: bad flags %d (FK_ATTN_Q_PRESCALED needs bf16, D = 64)", flags);
   FK_CHECK_ARG(Q && K && V && O && dO && LSE && dQ && dK && dV && delta_ws, "fk_attn_bwd: null pointer");
   FK_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0,
                "fk_attn_bwd: pointers must be 16-byte aligned");
@@ -974,7 +1502,7 @@ int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
   FK_CHECK_ARG(!rope_table || (Nq == Nk && D % 4 == 0 && ((uintptr_t)rope_table & 15) == 0), "fk_attn_bwd: fused inverse RoPE needs self-attention (Nq == Nk)");
   a.rope_table = rope_table; a.rope_bs = rope_bs; a.rope_off = (int)rope_off;
   FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_bwd: prefix / key-padding masks need both tables");
-  a.limits = limits; a.qfirst = qfirst;
+  a.limits = limits; a.qfirst = qfirst; a.flags = flags;
   FK_ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_bwd");
   return FK_OK;

@@ -55,6 +55,9 @@ struct NtArgs {
   // fused RoPE on the first rope_cols output columns (q and k of a packed qkv projection): row m is token
   // (m % rope_T) of its sample, rotated by table[(rope_off + m % rope_T)][(n % rope_D) / 2] = (cos, sin)
   const float* rope_table; int64_t rope_bs; int rope_T, rope_off, rope_D, rope_cols;
+  // the first rope_qcols columns (the queries) read their (cos, sin) pairs rope_qoff floats further on: a second copy of the table
+  // pre-multiplied by softmax_scale * log2(e), so Q leaves the projection in the exp2 domain of the attention kernels (FK_ATTN_Q_PRESCALED)
+  int rope_qcols; int64_t rope_qoff;
 };
 
 // sigmoid: the throughput (bf16) mode uses the hardware reciprocal (1 ulp), the fp32 parity mode an exact division
@@ -112,7 +115,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     if constexpr (PROPE) {
       if (rope_table && nb < p.rope_cols && col_ok) {
         int tt = mb % p.rope_T;
-        const float* tp = rope_table + (int64_t)(mb / p.rope_T) * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + (nb % p.rope_D) / 2) * 2;
+        const float* tp = rope_table + (nb < p.rope_qcols ? p.rope_qoff : (int64_t)0) + (int64_t)(mb / p.rope_T) * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + (nb % p.rope_D) / 2) * 2;
         auto fetch = [&](int ps, f32x4& lo, f32x4& hi) {
           if (mb + 8 * ps < p.M) { lo = *reinterpret_cast<const f32x4*>(tp); hi = *reinterpret_cast<const f32x4*>(tp + 4); }
           tt += 8;
@@ -167,7 +170,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
     if (do_rope && !PROPE) {
       tt = mb % p.rope_T;
       const int bb = mb / p.rope_T, dd = nb % p.rope_D;
-      tb = rope_table + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
+      tb = rope_table + (nb < p.rope_qcols ? p.rope_qoff : (int64_t)0) + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
     }
 #pragma unroll SWEEP_UNROLL
     for (int ps = 0; ps < 4 * NI; ++ps) {
@@ -1249,11 +1252,11 @@ int colsum_blocks(int64_t rows) {
 
 extern "C" {
 
-struct RopeSpec { const float* table; int64_t bs; int T, off, D, cols; };
+struct RopeSpec { const float* table; int64_t bs; int T, off, D, cols; int qcols; int64_t qoff; };
 
 static int launch_nt(const char* name, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                      int64_t N, int64_t K, const void* bias, const void* residual, int64_t ldr, int64_t res_rows, int dtype,
-                     int out_dtype, int mode, void* aux, int64_t ldaux, void* stream, RopeSpec rope = RopeSpec{nullptr, 0, 1, 0, 2, 0}) {
+                     int out_dtype, int mode, void* aux, int64_t ldaux, void* stream, RopeSpec rope = RopeSpec{nullptr, 0, 1, 0, 2, 0, 0, 0}) {
   FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "%s: bad dtype %d", name, dtype);
   FK_CHECK_ARG(out_dtype == dtype || out_dtype == FK_F32, "%s: out_dtype must equal dtype or be f32", name);
   const int vec = dtype == FK_BF16 ? 8 : 4;
@@ -1272,7 +1275,7 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
     FK_CHECK_ARG(vec_epi && rope.D % 8 == 0 && rope.cols % rope.D == 0 && rope.cols <= N && rope.T > 0 && M % rope.T == 0 &&
                  ((uintptr_t)rope.table & 15) == 0, "%s: fused RoPE needs the vector epilogue, D %% 8 == 0 and M %% T == 0", name);
   NtArgs p{A, B, C, bias, residual, lda, ldb, ldc, ldr, res_rows, (int)M, (int)N, (int)K, vec_epi ? 1 : 0, mode, aux, ldaux,
-           rope.table, rope.bs, rope.T, rope.off, rope.D, rope.cols};
+           rope.table, rope.bs, rope.T, rope.off, rope.D, rope.cols, rope.qcols, rope.qoff};
   const int64_t nwg = fk_cdiv(M, BM) * fk_cdiv(N, BN);
   dim3 grid((unsigned)nwg), block(NTHREADS);
   const size_t sh = 4 * TILE_BYTES;
@@ -1323,10 +1326,11 @@ int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 
 int fk_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                     int64_t K, const void* bias, const float* table, int64_t table_bs, int64_t T, int64_t pos_off, int64_t D,
-                    int64_t rot_cols, int dtype, void* stream) {
+                    int64_t rot_cols, int64_t q_cols, int64_t q_table_off, int dtype, void* stream) {
   FK_CHECK_ARG(table && T > 0 && D > 0 && rot_cols >= 0, "fk_gemm_nt_rope: bad rope arguments");
+  FK_CHECK_ARG(q_cols >= 0 && q_cols <= rot_cols && q_cols % 8 == 0 && q_table_off % 4 == 0, "fk_gemm_nt_rope: bad pre-scaled query table (q_cols %lld, offset %lld)", (long long)q_cols, (long long)q_table_off);
   return launch_nt("fk_gemm_nt_rope", A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, 0, dtype, dtype, 0, nullptr, 0, stream,
-                   RopeSpec{table, table_bs, (int)T, (int)pos_off, (int)D, (int)rot_cols});
+                   RopeSpec{table, table_bs, (int)T, (int)pos_off, (int)D, (int)rot_cols, (int)q_cols, q_table_off});
 }
 
 int fk_gemm_nt_swiglu(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G,

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import math
+import os
 import weakref
 
 import torch
@@ -291,18 +293,40 @@ def to_compute(x: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------------- rope spec
+_ROPE_PAIRS: dict = {}
+
+
 class Rope:
     """fp32 (cos, sin) table [Tc, D/2, 2] (or per-sample [B, Tc, D/2, 2]); the LAST T rows are used
     (models/brainformer.py:80,82)."""
-    __slots__ = ("table",)
+    __slots__ = ("table", "_src")
 
     def __init__(self, cache: Tensor):
         t = torch.view_as_real(cache) if cache.is_complex() else cache
         assert t.dtype == torch.float32 and t.shape[-1] == 2
         self.table = t.contiguous()
+        self._src = cache
 
     def pos_off(self, T: int) -> int:
         return self.table.shape[-3] - T
+
+    def pair(self, c: float):
+        """(table, table * c) as the two halves of ONE allocation: the second is what fk_gemm_nt_rope rotates the query columns
+        with, so that Q leaves the projection multiplied by c = softmax_scale * log2(e) (FK_ATTN_Q_PRESCALED).  Cached per cache
+        tensor (the model hands the same tensor to every layer); the entry dies with the tensor."""
+        src, key = self._src, id(self._src)
+        ent = _ROPE_PAIRS.get(key)
+        stamp = (src._version, float(c), src.data_ptr())
+        if ent is not None and ent[0]() is src and ent[1] == stamp:
+            return ent[2][0], ent[2][1]
+        both = torch.stack([self.table, self.table * float(c)]).contiguous()
+        _ROPE_PAIRS[key] = (weakref.ref(src, lambda _r, k=key: _ROPE_PAIRS.pop(k, None)), stamp, both)
+        return both[0], both[1]
+
+
+def _attn_prescale(D: int) -> bool:
+    """Queries pre-scaled by scale * log2(e) in the projection epilogue + the lean attention kernels: bf16, head_dim 64."""
+    return _COMPUTE_DTYPE == torch.bfloat16 and D == 64 and os.environ.get("FK_ATTN_NO_PRESCALE") is None
 
 
 # --------------------------------------------------------------------------------------------- functions
@@ -325,8 +349,14 @@ class AttnBranch(torch.autograd.Function):
             h, mean, rstd = x2, None, None
         HD = H * D
         bq = None if qkv_b is None else shadow([qkv_b])
+        prescale = False
         if rope is not None and D % 8 == 0 and (3 * HD) % 8 == 0:     # RoPE fused into the projection epilogue
-            qkv = K.gemm_nt_rope(h, shadow(qkv_w), bq, rope.table, N, rope.pos_off(N), D, 2 * HD)
+            prescale = _attn_prescale(D)
+            if prescale:
+                tab, qtab = rope.pair((1.0 / math.sqrt(D)) * 1.4426950408889634)
+                qkv = K.gemm_nt_rope(h, shadow(qkv_w), bq, tab, N, rope.pos_off(N), D, 2 * HD, q_cols=HD, q_table=qtab)
+            else:
+                qkv = K.gemm_nt_rope(h, shadow(qkv_w), bq, rope.table, N, rope.pos_off(N), D, 2 * HD)
             qkv3 = qkv.view(B, N, 3 * HD)
         else:
             qkv = K.gemm_nt(h, shadow(qkv_w), bias=bq)
@@ -334,10 +364,10 @@ class AttnBranch(torch.autograd.Function):
             if rope is not None:
                 K.rope_(qkv3, 2 * H, D, rope.table, rope.pos_off(N))
         q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
-        o, lse = K.attn_fwd(q, k, v, mask)
+        o, lse = K.attn_fwd(q, k, v, mask, q_prescaled=prescale)
         y = K.gemm_nt(o.view(M, HD), shadow([pw]), bias=None if pb is None else shadow([pb]),
                       residual=x2 if residual else None)
-        ctx.spec, ctx.has_ln, ctx.nw = spec, has_ln, len(qkv_w)
+        ctx.spec, ctx.has_ln, ctx.nw, ctx.prescale = spec, has_ln, len(qkv_w), prescale
         ctx.flags = (ln_b is not None, pb is not None, qkv_b is not None)
         ctx.ln_b = ln_b
         ctx.save_for_backward(x, ln_w, pw, *qkv_w, h if has_ln else None, mean, rstd, qkv, o, lse)
@@ -365,7 +395,8 @@ class AttnBranch(torch.autograd.Function):
         q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
         dq, dk, dv = (dqkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
         if rope is not None and D % 4 == 0:       # inverse RoPE fused into the dQ / dK stores
-            K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask, rope_table=rope.table, rope_off=rope.pos_off(N))
+            K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask, rope_table=rope.table, rope_off=rope.pos_off(N),
+                       q_prescaled=ctx.prescale)
         else:
             K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask)
             if rope is not None:

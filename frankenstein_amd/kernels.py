@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_KEYPAD, MASK_NONE, MASK_PREFIX, NORM_LAYER, NORM_RMS, call, lib
+from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_KEYPAD, MASK_NONE, MASK_PREFIX, NORM_LAYER, NORM_RMS, ATTN_Q_PRESCALED, call, lib
 
 Tensor = torch.Tensor
 
@@ -94,8 +94,10 @@ def gemm_nt(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
 
 
 def gemm_nt_rope(a: Tensor, w: Tensor, bias: Optional[Tensor], table: Tensor, T: int, pos_off: int, D: int,
-                 rot_cols: int) -> Tensor:
-    """out[M,N] = a @ w^T (+ bias) with RoPE applied to the first rot_cols columns (heads of width D); rows are B x T tokens."""
+                 rot_cols: int, q_cols: int = 0, q_table: Optional[Tensor] = None) -> Tensor:
+    """out[M,N] = a @ w^T (+ bias) with RoPE applied to the first rot_cols columns (heads of width D); rows are B x T tokens.
+    q_table: table * (softmax_scale * log2 e), in the SAME allocation as table; the first q_cols columns (the queries) are rotated
+    with it and so leave the projection pre-scaled for attn_fwd(..., q_prescaled=True)."""
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1
     assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[-1] == 2 and table.shape[-2] == D // 2
     M, Kd = a.shape
@@ -103,9 +105,15 @@ def gemm_nt_rope(a: Tensor, w: Tensor, bias: Optional[Tensor], table: Tensor, T:
     tbs = table.stride(0) if table.dim() == 4 else 0
     assert pos_off >= 0 and pos_off + T <= table.shape[-3] and M % T == 0
     out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    q_off = 0
+    if q_table is not None and q_cols:
+        assert q_table.shape == table.shape and q_table.dtype == torch.float32 and q_table.is_contiguous() and q_table.stride() == table.stride()
+        q_off = (q_table.data_ptr() - table.data_ptr()) // 4
+    else:
+        q_cols = 0
     with _timed(f"gemm_nt_rope:{M}x{N}x{Kd}"):
         call("fk_gemm_nt_rope", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), N, M, N, Kd, _ptr(bias),
-             table.data_ptr(), tbs, T, pos_off, D, rot_cols, fk_dtype(a), _stream())
+             table.data_ptr(), tbs, T, pos_off, D, rot_cols, q_cols, q_off, fk_dtype(a), _stream())
     return out
 
 
@@ -208,8 +216,9 @@ def _bnhd(t: Tensor):
 
 
 def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optional[float] = None,
-             out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-    """q [B,Nq,H,D], k/v [B,Nk,H,D] (strided views ok) -> (o [B,Nq,H,D], lse [B,H,Nq] fp32)."""
+             out: Optional[Tensor] = None, q_prescaled: bool = False) -> Tuple[Tensor, Tensor]:
+    """q [B,Nq,H,D], k/v [B,Nk,H,D] (strided views ok) -> (o [B,Nq,H,D], lse [B,H,Nq] fp32).
+    q_prescaled: q already holds scale * log2(e) * q (gemm_nt_rope's q_table; bf16, D = 64 only)."""
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     assert k.shape == (B, Nk, H, D) and v.shape == (B, Nk, H, D) and q.dtype == k.dtype == v.dtype
@@ -221,13 +230,13 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optio
     with _timed(f"attn_fwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
       call("fk_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
            qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst),
-           sc, fk_dtype(q), _stream())
+           sc, ATTN_Q_PRESCALED if q_prescaled else 0, fk_dtype(q), _stream())
     return out, lse
 
 
 def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
              mask: Mask = NO_MASK, scale: Optional[float] = None, rope_table: Optional[Tensor] = None,
-             rope_off: int = 0) -> None:
+             rope_off: int = 0, q_prescaled: bool = False) -> None:
     """Writes dq/dk/dv (same strides as q/k/v); do must have o's strides.  rope_table: also un-rotate dq/dk (RoPE backward)."""
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
@@ -240,7 +249,8 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
       call("fk_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
            mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst), sc, _ptr(rope_table),
-           0 if rope_table is None or rope_table.dim() == 3 else rope_table.stride(0), rope_off, fk_dtype(q), _stream())
+           0 if rope_table is None or rope_table.dim() == 3 else rope_table.stride(0), rope_off,
+           ATTN_Q_PRESCALED if q_prescaled else 0, fk_dtype(q), _stream())
 
 
 # ------------------------------------------------------------------------------------------- norms

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FK_VERSION 100
+#define FK_VERSION 200
 
 #define FK_OK 0
 #define FK_EINVAL (-1)       /* bad shape / dtype / alignment / null pointer */
@@ -32,6 +32,11 @@ extern "C" {
 
 enum { FK_F32 = 0, FK_BF16 = 1 };
 enum { FK_MASK_NONE = 0, FK_MASK_CAUSAL = 1, FK_MASK_BLOCK_CAUSAL = 2, FK_MASK_PREFIX = 3, FK_MASK_KEYPAD = 4 };
+/* fk_attn_* flags.  FK_ATTN_Q_PRESCALED: Q already holds scale * log2(e) * q (written so by fk_gemm_nt_rope's pre-scaled query
+ * table), bf16 with D = 64 only: the kernels then work in the exp2 domain with the row constants (running reference maximum,
+ * -LSE, -delta) as the initial MFMA accumulators, i.e. without any per-score multiply / subtract.  dQ, dK, dV are the same
+ * quantities as without the flag (gradients w.r.t. the UNSCALED q, k, v).                                                  */
+enum { FK_ATTN_Q_PRESCALED = 1 };
 enum { FK_NORM_LAYER = 0, FK_NORM_RMS = 1 };
 enum { FK_ACT_SWIGLU = 0, FK_ACT_GELU = 1 };
 
@@ -48,10 +53,13 @@ int fk_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
                int out_dtype, void* stream);
 /* fk_gemm_nt_rope: fk_gemm_nt (+ bias) with apply_rope (models/brainformer.py:70-91) fused into the epilogue: the first
  * rot_cols output columns (q and k of a packed q|k|v projection, heads of width D) of row m are rotated by
- * table[m / T][pos_off + m % T][(n % D) / 2] = (cos, sin)  (table_bs = 0: one cache shared by all samples).           */
+ * table[m / T][pos_off + m % T][(n % D) / 2] = (cos, sin)  (table_bs = 0: one cache shared by all samples).
+ * The first q_cols columns (the queries; 0 = none) take their pairs from table + q_table_off floats instead: a second copy
+ * of the cache multiplied by softmax_scale * log2(e), which hands Q to fk_attn_* in the FK_ATTN_Q_PRESCALED form with a
+ * single rounding (models/brainformer.py:153-168: the 1/sqrt(dh) of SDPA folded into the rotation).                      */
 int fk_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                     int64_t K, const void* bias, const float* table, int64_t table_bs, int64_t T, int64_t pos_off, int64_t D,
-                    int64_t rot_cols, int dtype, void* stream);
+                    int64_t rot_cols, int64_t q_cols, int64_t q_table_off, int dtype, void* stream);
 /* SwiGLU MLP fused into the projection epilogues (models/brainformer.py:124 and its autograd).  Hidden units use the
  * INTERLEAVED layout: for every 4 hidden units, 4 columns of h1 = w1 x followed by 4 columns of h3 = w3 x (W13 rows are
  * packed the same way, see fk_cast_pack_rows).
@@ -84,13 +92,13 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
                 int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
                 int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
-                const int32_t* limits, const int32_t* qfirst, float scale, int dtype, void* stream);
+                const int32_t* limits, const int32_t* qfirst, float scale, int flags, int dtype, void* stream);
 int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                 void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                 int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
                 int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
-                const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int dtype,
-                void* stream);
+                const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int flags,
+                int dtype, void* stream);
 
 /* ---- normalisation (nn.LayerNorm: models/brainformer.py:237,239,252,254,287,500; F.layer_norm models/gpt2_model.py:27;
  *      RMSNorm models/brainformer.py:221-232).  x,y [rows, dim] contiguous; gamma/beta fp32 (beta may be NULL);

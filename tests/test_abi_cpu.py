@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_symbol(built):
     for s in declared_symbols():
         assert hasattr(h, s), f"{s} declared in include/franken_hip.h but not exported"
     lib = _lib.lib()
-    assert lib.fk_version() == 100
+    assert lib.fk_version() == 200
     assert lib.fk_last_error() is not None
 
 
@@ -46,8 +46,12 @@ def test_argument_validation_needs_no_gpu(built):
     assert rc == -1 and b"dtype" in lib.fk_last_error()
     rc = lib.fk_gemm_nt(16, 12, 16, 12, 16, 8, 8, 8, 12, None, None, 0, 0, _lib.FK_BF16, _lib.FK_BF16, None)
     assert rc == -1 and b"multiples" in lib.fk_last_error()
-    rc = lib.fk_attn_fwd(16, 16, 16, 16, None, 1, 1, 8, 8, 24, 0, 24, 0, 24, 0, 24, 0, 24, 0, 0, 0, 0, None, None, 1.0, 0, None)
+    rc = lib.fk_attn_fwd(16, 16, 16, 16, None, 1, 1, 8, 8, 24, 0, 24, 0, 24, 0, 24, 0, 24, 0, 0, 0, 0, None, None, 1.0, 0, 0, None)
     assert rc == -1 and b"head_dim" in lib.fk_last_error()
+    # FK_ATTN_Q_PRESCALED exists for bf16 / head_dim 64 only
+    rc = lib.fk_attn_fwd(16, 16, 16, 16, None, 1, 1, 8, 8, 32, 0, 32, 0, 32, 0, 32, 0, 32, 0, 0, 0, 0, None, None, 1.0,
+                         _lib.ATTN_Q_PRESCALED, _lib.FK_BF16, None)
+    assert rc == -1 and b"FK_ATTN_Q_PRESCALED" in lib.fk_last_error()
     rc = lib.fk_patchify(16, 16, 1, 10, 4, 3, 8, 0, None)
     assert rc == -1
 

@@ -249,6 +249,98 @@ def test_attention_fwd_bwd(K, dtype, case):
     close(dv, vr.grad, dtype, atol32=5e-5, atol16=4e-2)
 
 
+PS_CASES = [
+    # B, H, Nq, Nk, kind, c, spike      (bf16, D = 64: the FK_ATTN_Q_PRESCALED kernels)
+    (2, 3, 256, 256, 0, 0, 0.0),
+    (1, 2, 200, 200, 2, 8, 0.0),          # ragged, boundary sub-tiles everywhere
+    (2, 2, 333, 333, 1, 0, 0.0),          # causal, ragged
+    (1, 4, 32, 300, 0, 0, 0.0),           # cross-shaped (Nq << Nk)
+    (1, 2, 512, 512, 2, 256, 0.0),        # the benchmark's block size: no boundary tiles at all
+    (1, 2, 640, 640, 2, 256, 40.0),       # a late key that outgrows reference 0 by far: lean loop -> fallback loop
+    (1, 2, 384, 384, 2, 128, -3.0e3),     # every score hugely negative: the window test keeps the classic loop
+]
+
+
+@pytest.mark.parametrize("case", PS_CASES)
+def test_attention_prescaled_q(K, case):
+    """FK_ATTN_Q_PRESCALED (Q' = scale * log2(e) * q stored in bf16 by the projection epilogue): forward, LSE and all three
+    gradients (w.r.t. the UNSCALED q) against the fp32 oracle evaluated at q = Q' / (scale * log2 e)."""
+    B, H, Nq, Nk, kind, c, spike = case
+    D, dtype = 64, torch.bfloat16
+    cq = (1.0 / math.sqrt(D)) * 1.4426950408889634
+    qp = q(rnd(B, Nq, H * D, seed=1) * cq * 2.0, dtype)                 # Q' as the device sees it
+    kv = rnd(B, Nk, 2 * H * D, seed=2)
+    if spike > 0:
+        # key 600 of head 0 strongly aligned with query 610: its score outgrows everything seen before by far
+        kv[0, 600, :D] = spike * (qp[0, 610, :D] / cq) / 8.0
+    if spike < 0:
+        # head 0: a component shared by all keys puts every score near spike * 8 / sqrt(D) (far below the window of reference 0)
+        kv[..., 0] = 8.0
+        qp[..., 0] = q(torch.tensor(spike * cq), dtype)
+    kv = q(kv, dtype)
+    do = rnd(B, Nq, H, D, seed=3)
+    qd = dev(qp, dtype).view(B, Nq, H, D)
+    kvd = dev(kv, dtype)
+    kd, vd = kvd[..., : H * D].unflatten(-1, (H, D)), kvd[..., H * D:].unflatten(-1, (H, D))
+    m = K.Mask(kind, c)
+    o, lse = K.attn_fwd(qd, kd, vd, m, q_prescaled=True)
+    qr = (qp.view(B, Nq, H, D) / cq).requires_grad_(True)
+    kr = q(kv[..., : H * D], dtype).reshape(B, Nk, H, D).requires_grad_(True)
+    vr = q(kv[..., H * D:], dtype).reshape(B, Nk, H, D).requires_grad_(True)
+    mt = mask_tensor(kind, c, Nq, Nk)
+    oref = ref_attn(qr, kr, vr, mt)
+    close(o, oref, dtype, atol16=2e-2)
+    sfull = (qr.transpose(1, 2) @ kr.transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
+    if mt is not None:
+        sfull = sfull.masked_fill(~mt, float("-inf"))
+    lref = torch.logsumexp(sfull, -1)
+    torch.testing.assert_close(lse.cpu(), lref.detach(), atol=3e-2, rtol=2e-3)
+    oref.backward(q(do, dtype))
+    dq = torch.empty_like(qd)
+    dkv = torch.empty_like(kvd)
+    dk, dv = dkv[..., : H * D].unflatten(-1, (H, D)), dkv[..., H * D:].unflatten(-1, (H, D))
+    K.attn_bwd(qd, kd, vd, o, dev(do, dtype), lse, dq, dk, dv, m, q_prescaled=True)
+    close(dq, qr.grad, dtype, atol16=4e-2)
+    close(dk, kr.grad, dtype, atol16=4e-2 * max(1.0, float(kr.grad.abs().max()) / 4))
+    close(dv, vr.grad, dtype, atol16=4e-2)
+    # the two forms of the same problem agree with each other at bf16 rounding level
+    qun = dev(qr.detach().reshape(B, Nq, H, D), dtype)
+    o2, lse2 = K.attn_fwd(qun, kd, vd, m)
+    assert float((o2.float() - o.float()).abs().max()) < 6e-2
+
+
+def test_attention_prescaled_q_masks_from_tables(K):
+    """prefix (MAE sub-mask) and key-padding tables on the pre-scaled path, incl. fully masked query rows (-> 0, LSE = +inf)."""
+    B, H, N, n, D, Cb = 2, 2, 700, 260, 64, 16
+    dtype = torch.bfloat16
+    cq = (1.0 / math.sqrt(D)) * 1.4426950408889634
+    ids = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(10 + i))[:n].sort()[0] for i in range(B)])
+    dense = ((ids[:, None, :] // Cb) <= (ids[:, :, None] // Cb))[:, None]            # [B, 1, n, n]
+    valid = torch.ones(B, n, dtype=torch.bool)
+    valid[0, 200:] = False
+    valid[1, 37:41] = False
+    pad = (valid[:, None, :, None] & valid[:, None, None, :])
+    for mask, mt in ((K.Mask.from_token_ids(dev(ids), dev(ids), Cb), dense),
+                     (K.Mask(4, 0, 0, 0, dev(valid.to(torch.int32)), dev(valid.to(torch.int32))), pad)):
+        qp = q(rnd(B, n, H, D, seed=1) * cq * 2.0, dtype)
+        kv, vv, do = (rnd(B, n, H, D, seed=s_) for s_ in (2, 3, 4))
+        qd, kd, vd = dev(qp, dtype), dev(kv, dtype), dev(vv, dtype)
+        o, lse = K.attn_fwd(qd, kd, vd, mask, q_prescaled=True)
+        qr = (qp / cq).requires_grad_(True)
+        kr, vr = (q(t_, dtype).requires_grad_(True) for t_ in (kv, vv))
+        # fully masked rows: 0 (torch >= 2.1 semantics)
+        oref = R.sdpa_zero_fully_masked(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), mt.expand(B, 1, n, n)).transpose(1, 2)
+        close(o, oref, dtype, atol16=2e-2)
+        rows_dead = ~mt.expand(B, 1, n, n).any(-1)[:, 0]                        # [B, n]
+        assert bool(torch.isinf(lse.cpu()[rows_dead[:, None, :].expand(B, H, n)]).all())
+        (oref * q(do, dtype)).sum().backward()
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        K.attn_bwd(qd, kd, vd, o, dev(do, dtype), lse, dq, dk, dv, mask, q_prescaled=True)
+        close(dq, qr.grad, dtype, atol16=4e-2)
+        close(dk, kr.grad, dtype, atol16=4e-2)
+        close(dv, vr.grad, dtype, atol16=4e-2)
+
+
 def test_attention_mask_offsets_and_spike(K):
     # sliced mask (t_q < t_k, models/brainformer.py:160-162) and a forced running-max jump (online softmax rescale)
     B, H, Nq, Nk, D = 1, 2, 40, 200, 32

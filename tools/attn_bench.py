@@ -15,9 +15,13 @@ do = (torch.randn(B, N, H, D, device=dev, generator=g) * 0.5).to(torch.bfloat16)
 dqkv = torch.empty_like(qkv)
 dq, dk, dv = (dqkv[..., i * H * D:(i + 1) * H * D].unflatten(-1, (H, D)) for i in range(3))
 vis = 0.5 * N * N * (1 + Cb / N)
-cases = {"attn_fwd": (lambda: K.attn_fwd(q, k, v, mask), 4 * B * H * vis * D),
-         "attn_bwd": (lambda: K.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, mask), 10 * B * H * vis * D)}
+PS = os.environ.get("ATTN_PS", "1") != "0"      # the pre-scaled-Q kernels (what the training step runs); ATTN_PS=0: the generic ones
+if PS:
+    o, lse = K.attn_fwd(q, k, v, mask, q_prescaled=True)
+cases = {"attn_fwd": (lambda: K.attn_fwd(q, k, v, mask, q_prescaled=PS), 4 * B * H * vis * D),
+         "attn_bwd": (lambda: K.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, mask, q_prescaled=PS), 10 * B * H * vis * D)}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+print("pre-scaled Q kernels" if PS else "generic kernels")
 for f, _ in cases.values(): f()
 torch.cuda.synchronize()
 for name, (f, fl) in cases.items():
