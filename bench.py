@@ -6,7 +6,11 @@ SwiGLU 1536; window 600, patch 25 -> N=6144 tokens; 2-block perceiver with 32 qu
 batch 32 x T=600 x 256 electrodes, bf16 compute / fp32 masters.  One step = forward + backward + (DP gradient
 all-reduce) + clip_grad_value_ + AdamW over one synthetic batch already resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment), or plain `python bench.py --gpus N`, in which case this process starts that launcher itself as a
+CHILD process before anything touches the GPU, relays rank 0's JSON line and exits with the child's code.  One rank per GPU, RCCL.
 
 Prints ONE JSON line on rank 0.  `value` = total frames/s of the whole job (frames = B*T input time-steps).
 `roofline` is for the dominant kernel family (measured live with HIP events on the launch stream);
@@ -104,6 +108,52 @@ def mfma_util_pmc():
         return None
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: run `torch.distributed.run` as a child process (fresh ranks; this process
+    has not initialised the GPU and never does) and relay its output."""
+    import socket
+    import subprocess
+    if not args.dry_run:
+        n = torch.cuda.device_count()               # counting devices does not initialise HIP
+        if n < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) visible on this host; "
+                  f"run with --gpus <= {n}, or launch one rank per GPU on a node that has {args.gpus}", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def dry_run(args, rank, world):
+    """Launcher / rendezvous / timing-reduction plumbing without a GPU (gloo): what tests/test_host_cpu.py drives at world size 2."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "dry_run": True, "n_gpus": world,
+                          "world": world, "steps": args.steps, "warmup": args.warmup, "max_rank_time_s": float(t)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def parity_block():
+    """bf16-vs-reference numbers at the benchmarked shape, measured by tests/test_models_gpu.py::test_cfg2_b1_bf16_vs_reference and
+    committed under profiles/ (None when that file is absent)."""
+    try:
+        return json.load(open(ROOT / "profiles" / "r02_parity_cfg2_bf16.json"))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,12 +164,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true")
     ap.add_argument("--all-timers", action="store_true", help="HIP-event timing of every kernel family (default: the roofline kernel family only)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous only, gloo on the CPU (no GPU work)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local}, visible devices: {torch.cuda.device_count()})", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -197,7 +257,8 @@ def main():
                     "flops_per_launch": fl, "avg_launch_ms": round(avg_s * 1e3, 3)}
         out = {
             "metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "value": round(value, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": world, "world": world, "rccl": (".".join(map(str, torch.cuda.nccl.version())) if world > 1 else None),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "brainformer-small (6L d=384 6x64 heads, N=6144 tokens) + 2-block perceiver, L1 head; "
                                    "fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world, "frames_T": T,
@@ -210,6 +271,7 @@ def main():
                               "note": "whole step per GPU: frames/s x 1.8173 GFLOP/frame (SURVEY §8d)"},
             "kernel_families": detail,
             "loss": round(float(loss), 5),
+            "parity": parity_block(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -169,6 +169,14 @@ FK_DEV void dma_tile_bf16_d64(const bf16_t* base, int64_t rs, int row0, int nrow
   }
 }
 
+// one 8-row group (one wave instruction) of such a tile
+FK_DEV void dma_group_bf16_d64(const bf16_t* base, int64_t rs, int row0, int nrows, char* img, int grp, int lane) {
+  const int row = grp * 8 + (lane >> 3);
+  const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+  const unsigned off = __umul24((unsigned)min(row0 + row, nrows - 1), (unsigned)rs) + (unsigned)(((lane & 7) ^ f) * 8);
+  __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off), (lds_void_t*)(img + grp * 1024), 16, 0, 0);
+}
+
 // The same loader as a cursor over consecutive tiles: the per-lane source pointers are computed once and advanced by ROWS rows per
 // tile (one 64-bit add per instruction instead of a clamp, two 32-bit multiplies and a 64-bit multiply-add, all quarter-rate VALU work
 // that sat in every tile of the hot loops); only a tile that reaches past `nrows` takes the clamping path above.  Used where registers
@@ -869,6 +877,17 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
 //             the first visible tile of a row, and afterwards only if a score outgrows the reference by more than ~40 (log2 units).
 //             bf16 has fp32's exponent range, so P up to 2^40 keeps the same relative precision as P <= 1.
 //   backward: S' = Q'K^T - LSE*log2(e) and dP' = dO V^T - delta start from the row constants, P = exp2(S'), dS = P * dP'.
+#ifdef FK_STAMP
+// diagnostic build only (tools/build_variant.sh stamp ... -DFK_STAMP): cycles per loop segment, summed over waves; never in the product
+__device__ unsigned long long fk_stamp_acc[16];
+#define FK_ST_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FK_ST(i) { const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; }
+#define FK_ST_FLUSH(base) if (lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&fk_stamp_acc[(base) + i_], st_acc[i_]); }
+#else
+#define FK_ST_DECL
+#define FK_ST(i)
+#define FK_ST_FLUSH(base)
+#endif
 constexpr float PS_REDO = 1.0e12f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -912,12 +931,19 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
   const int full_vis_end = kv_limit(p, b, wave_q_first);
 
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): from here on vmcnt counts only LDS-DMA instructions (see attn_fwd_kernel)
+  // K and V tile t into ring slot sl: 16 one-KiB pieces per tile, NW <= 8: 16 / NW per wave; NW = 16: one piece per wave
+  auto dma_kv = [&](int t, int sl) {
+    if constexpr (NW == 16) {
+      if (wave < 8) dma_group_bf16_d64(Kp, p.k_rs, t * BKV, p.Nk, kimg(sl), wave, lane);
+      else dma_group_bf16_d64(Vp, p.v_rs, t * BKV, p.Nk, vimg(sl), wave - 8, lane);
+    } else {
+      dma_tile_bf16_d64<BKV, NW>(Kp, p.k_rs, t * BKV, p.Nk, kimg(sl), wave, lane);
+      dma_tile_bf16_d64<BKV, NW>(Vp, p.v_rs, t * BKV, p.Nk, vimg(sl), wave, lane);
+    }
+  };
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt)
-    if (pt < ntiles) {
-      dma_tile_bf16_d64<BKV, NW>(Kp, p.k_rs, pt * BKV, p.Nk, kimg(pt), wave, lane);
-      dma_tile_bf16_d64<BKV, NW>(Vp, p.v_rs, pt * BKV, p.Nk, vimg(pt), wave, lane);
-    }
+    if (pt < ntiles) dma_kv(pt, pt);
   float m = -INFINITY, l = 0.0f;        // m: this row's reference (exp2 domain); -inf = none yet
   f32x16 o[2];
   zero_acc(o);
@@ -932,7 +958,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
     // retire tile t's DMA (oldest of this wave) but leave tile t+1's in flight across the barrier; the barrier also guarantees every
     // wave is done reading slot (t+2)%3 (= tile t-1), which is refilled right after it.
     if (t + 1 < ntiles) {
-      if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if constexpr (NW == 16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     if (t + 1 >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -940,8 +967,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
     asm volatile("" ::: "memory");
     if (t + 2 < ntiles) {
       const int ns = slot >= 1 ? slot - 1 : 2;     // (t + 2) % 3
-      dma_tile_bf16_d64<BKV, NW>(Kp, p.k_rs, (t + 2) * BKV, p.Nk, kimg(ns), wave, lane);
-      dma_tile_bf16_d64<BKV, NW>(Vp, p.v_rs, (t + 2) * BKV, p.Nk, vimg(ns), wave, lane);
+      dma_kv(t + 2, ns);
     }
   };
   // S2 = Q' K^T of sub-tile j (accumulator starts from literal zero), masked on boundary sub-tiles
@@ -964,7 +990,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kbase + (r & 3) + 8 * (r >> 2);
-        if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))))) sc[r] = -INFINITY;
+        const bool vis = key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)));
+        sc[r] = vis ? sc[r] : -INFINITY;
       }
     }
   };
@@ -1067,13 +1094,18 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------- dQ (pre-scaled Q)
-__global__ __launch_bounds__(NT) void attn_bwd_dq_ps_kernel(AttnArgs p) {
+// NW waves per workgroup (32 query rows each): every staged K/V tile costs its 16 LDS-DMA pieces once per workgroup, and an LDS-DMA
+// piece costs the issuing wave 60-180 cycles (MI355X_MICROARCH.md, cycle constants), so 8 waves halve that share per MFMA
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) {
   using T = bf16_t;
-  constexpr int D = 64;
+  constexpr int D = 64, BQ = NW * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int IMG = BKV * 128;
+  // 3-slot ring: tiles t+1 and t+2 in flight while tile t is consumed (with two slots the single tile of prefetch distance left the
+  // workgroup waiting at the end-of-tile barrier: 0.25 ms of a 1.8 ms launch in the dK/dV kernel, measured by leaving the DMA out)
+  constexpr int IMG = BKV * 128, NS = 3, PCS = 2 * (BKV / 8) / NW;   // PCS: LDS-DMA pieces per wave and tile (K + V)
   auto kimg = [&](int i) -> char* { return smem + i * IMG; };
-  auto vimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
+  auto vimg = [&](int i) -> char* { return smem + (NS + i) * IMG; };
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (p.Nq + BQ - 1) / BQ;
@@ -1127,23 +1159,30 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_ps_kernel(AttnArgs p) {
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
   const int full_vis_end = kv_limit(p, b, wave_q_first);
 
-  DmaCursor<BKV> kcur, vcur;
+  DmaCursor<BKV, NW> kcur, vcur;
+  static_assert(PCS == 4 || PCS == 2, "vmcnt immediates below");
   if (ntiles > 0) {
     kcur.init(Kp, p.k_rs, 0, wave, lane);
     vcur.init(Vp, p.v_rs, 0, wave, lane);
     kcur.next(Kp, p.k_rs, 0, p.Nk, kimg(0), wave, lane);
     vcur.next(Vp, p.v_rs, 0, p.Nk, vimg(0), wave, lane);
+    if (ntiles > 1) {
+      kcur.next(Kp, p.k_rs, BKV, p.Nk, kimg(1), wave, lane);
+      vcur.next(Vp, p.v_rs, BKV, p.Nk, vimg(1), wave, lane);
+    }
   }
-  dma_wait_barrier();
+  // (the Q / dO / O / LSE register loads above are older than every DMA, so a counted wait covers them too)
+  if (ntiles > 1) { if constexpr (PCS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  else dma_wait_barrier();
   f32x16 dq[2];
   zero_acc(dq);
 
   auto tile_step = [&](auto SL, int t) {
     constexpr int SLOT = decltype(SL)::value;
     const int kb = t * BKV;
-    if (t + 1 < ntiles) {
-      kcur.next(Kp, p.k_rs, kb + BKV, p.Nk, kimg(SLOT ^ 1), wave, lane);
-      vcur.next(Vp, p.v_rs, kb + BKV, p.Nk, vimg(SLOT ^ 1), wave, lane);
+    if (t + 2 < ntiles) {     // slot (SLOT + 2) % 3 held tile t-1: every wave left it at the barrier that ended the previous step
+      kcur.next(Kp, p.k_rs, kb + 2 * BKV, p.Nk, kimg((SLOT + 2) % NS), wave, lane);
+      vcur.next(Vp, p.v_rs, kb + 2 * BKV, p.Nk, vimg((SLOT + 2) % NS), wave, lane);
     }
     const char* kt = kimg(SLOT);
     const char* vt = vimg(SLOT);
@@ -1191,11 +1230,14 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_ps_kernel(AttnArgs p) {
         }
       }
     }
-    dma_wait_barrier();
+    // tile t+1 has landed (everything but this step's own pieces), tile t+2 stays in flight across the barrier
+    if (t + 2 < ntiles) { if constexpr (PCS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    else dma_wait_barrier();
   };
-  for (int t = 0; t < ntiles; t += 2) {
+  for (int t = 0; t < ntiles; t += 3) {
     tile_step(std::integral_constant<int, 0>{}, t);
     if (t + 1 < ntiles) tile_step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < ntiles) tile_step(std::integral_constant<int, 2>{}, t + 2);
   }
   T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
   if (p.rope_table && q_ok)
@@ -1205,19 +1247,22 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_ps_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------- dK, dV (pre-scaled Q)
-__global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p) {
   using T = bf16_t;
-  constexpr int D = 64, TQ = 64;
+  constexpr int D = 64, TQ = 64, BK = NW * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int IMG = TQ * 128;
+  // 3-slot ring (see attn_bwd_dq_ps_kernel): tiles t+1 and t+2 in flight while tile t is consumed
+  constexpr int IMG = TQ * 128, NS = 3, PCS = 2 * (TQ / 8) / NW;   // PCS: LDS-DMA pieces per wave and tile (Q + dO)
+  static_assert(PCS == 4 || PCS == 2, "vmcnt immediates below");
   auto qimg = [&](int i) -> char* { return smem + i * IMG; };
-  auto gimg = [&](int i) -> char* { return smem + (2 + i) * IMG; };
-  float* stats = reinterpret_cast<float*>(smem + 4 * IMG);   // [2 buffers][2 (-lse2, -delta)][TQ]
+  auto gimg = [&](int i) -> char* { return smem + (NS + i) * IMG; };
+  float* stats = reinterpret_cast<float*>(smem + 2 * NS * IMG);   // [NS buffers][2 (-lse2, -delta)][TQ]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nkb = (p.Nk + 127) / 128;
+  const int nkb = (p.Nk + BK - 1) / BK;
   const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = (int)(L / nkb), b = bh / p.H, hd = bh % p.H, k0 = (int)(L % nkb) * 128;
+  const int bh = (int)(L / nkb), b = bh / p.H, hd = bh % p.H, k0 = (int)(L % nkb) * BK;
   const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
   const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
   const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
@@ -1243,98 +1288,121 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p) {
   const int full_vis_q = q_first(p, b, min(k0 + wave * 32 + 31, p.Nk - 1));
   const int64_t stat0 = ((int64_t)b * p.H + hd) * p.Nq;
 
-  float st_l = 0.0f, st_d = 0.0f;
-  bool st_ok = false;
-  auto load_stats = [&](int qb) {      // raw loads only (see attn_bwd_dkdv_kernel)
+  // Row statistics travel one step behind their tile's DMA: loaded (wave 0, raw loads only: arithmetic on the value would force an
+  // early vmcnt wait) when the tile is requested, two tiles ahead, and written to LDS one step later, when only the NEXT request is
+  // younger in the vmcnt queue: the compiler's wait for these two registers then leaves that request in flight.
+  float st_l = 0.0f, st_d = 0.0f, nx_l = 0.0f, nx_d = 0.0f;
+  bool st_ok = false, nx_ok = false;
+  auto load_stats = [&](int qb) {
+    st_l = nx_l; st_d = nx_d; st_ok = nx_ok;
     if (tid < TQ) {
       const int q = qb + tid;
-      st_ok = q < p.Nq;
-      if (st_ok) {
-        st_l = p.LSE[stat0 + q];
-        st_d = p.delta[stat0 + q];
+      nx_ok = q < p.Nq;
+      if (nx_ok) {
+        nx_l = p.LSE[stat0 + q];
+        nx_d = p.delta[stat0 + q];
       }
     }
   };
-  auto store_stats = [&](int buf) {
+  auto store_stats = [&](int buf) {      // the OLDER set (st_*)
     if (tid < TQ) {
       stats[buf * 2 * TQ + tid] = st_ok ? -(st_l * LOG2E) : -INFINITY;
       stats[buf * 2 * TQ + TQ + tid] = st_ok ? -st_d : 0.0f;
     }
   };
   if (ntiles > 0) {
-    dma_tile_bf16_d64<TQ>(Qp, p.q_rs, qs, p.Nq, qimg(0), wave, lane);
-    dma_tile_bf16_d64<TQ>(Gp, p.o_rs, qs, p.Nq, gimg(0), wave, lane);
+    dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qs, p.Nq, qimg(0), wave, lane);
+    dma_tile_bf16_d64<TQ, NW>(Gp, p.o_rs, qs, p.Nq, gimg(0), wave, lane);
     load_stats(qs);
+    if (ntiles > 1) {
+      dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qs + TQ, p.Nq, qimg(1), wave, lane);
+      dma_tile_bf16_d64<TQ, NW>(Gp, p.o_rs, qs + TQ, p.Nq, gimg(1), wave, lane);
+    }
+    load_stats(qs + TQ);                 // (rows past Nq load nothing)  st_* = tile 0, nx_* = tile 1
     store_stats(0);
   }
-  dma_wait_barrier();
+  // tile 0 and its statistics have landed; tile 1 (pieces + wave 0's two statistics loads) may stay in flight
+  auto wait_next = [&]() {
+    if (wave == 0) { if constexpr (PCS == 4) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    else { if constexpr (PCS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  };
+  if (ntiles > 1) wait_next(); else dma_wait_barrier();
   f32x16 dk[2], dv[2];
   zero_acc(dk);
   zero_acc(dv);
+  FK_ST_DECL
 
   auto tile_step = [&](auto SL, int t) {
     constexpr int SLOT = decltype(SL)::value;
     const int qb = qs + t * TQ;
-    if (t + 1 < ntiles) {
-      dma_tile_bf16_d64<TQ>(Qp, p.q_rs, qb + TQ, p.Nq, qimg(SLOT ^ 1), wave, lane);
-      dma_tile_bf16_d64<TQ>(Gp, p.o_rs, qb + TQ, p.Nq, gimg(SLOT ^ 1), wave, lane);
-      load_stats(qb + TQ);
-    }
+    // request tile t+2: slot (SLOT + 2) % 3 held tile t-1, which every wave left at the barrier that ended the previous step.  WHERE in the
+    // step the request is issued matters: right after the barrier all waves of the workgroup issue their pieces at once and queue behind
+    // each other in the CU's one vector-memory path (190 cycles per piece measured with -DFK_STAMP)
+    auto request = [&]() {
+      if (t + 2 < ntiles) {
+        dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qb + 2 * TQ, p.Nq, qimg((SLOT + 2) % NS), wave, lane);
+        dma_tile_bf16_d64<TQ, NW>(Gp, p.o_rs, qb + 2 * TQ, p.Nq, gimg((SLOT + 2) % NS), wave, lane);
+      }
+      if (t + 1 < ntiles) load_stats(qb + 2 * TQ);      // st_* <- tile t+1 (requested one step ago), nx_* <- tile t+2 (nothing past Nq)
+    };
+#ifndef FK_DMA_POS
+#define FK_DMA_POS 0
+#endif
+    if constexpr (FK_DMA_POS == 0) request();
+    FK_ST(0)
     const char* qt = qimg(SLOT);
     const char* gt = gimg(SLOT);
     const float* stl = stats + SLOT * 2 * TQ;
     const float* std_ = stl + TQ;
     const bool boundary = (qb < full_vis_q) || (k0 + wave * 32 + 31 >= p.Nk);   // wave-uniform
-    // phase 1: S' = Q'K^T - lse2 and dP' = dO V^T - delta: the accumulators start from the staged row constants
-    f32x16 sc[2], dp[2];
+    // the two 32-row query halves of the tile one after the other: 32 live score registers instead of 64 leave the scheduler room to
+    // request the next LDS fragments ahead of the MFMAs that consume them
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+      // S' = Q'K^T - lse2 and dP' = dO V^T - delta: the accumulators start from the staged row constants
+      f32x16 sc, dp;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + 32 * u + 8 * g + 4 * lh);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(std_ + 32 * u + 8 * g + 4 * lh);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sc[u][4 * g + j] = l4[j]; dp[u][4 * g + j] = d4[j]; }
+        for (int j = 0; j < 4; ++j) { sc[4 * g + j] = l4[j]; dp[4 * g + j] = d4[j]; }
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         Frag<T> qf, gf;
         img_row<T, D>(qf, qt, 32 * u + li, s, lh);
         img_row<T, D>(gf, gt, 32 * u + li, s, lh);
-        mma32<T>(sc[u], qf, kf[s]);   // S'[q][key]
-        mma32<T>(dp[u], gf, vf[s]);   // dP'[q][key]
+        mma32<T>(sc, qf, kf[s]);   // S'[q][key]
+        mma32<T>(dp, gf, vf[s]);   // dP'[q][key]
       }
-    }
-    // phase 2: P = exp2(S'), dS = P dP'
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
+      FK_ST(1)
+      // P = exp2(S'), dS = P dP'
       if (!boundary) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(sc[u][r]);
-          sc[u][r] = pv;
-          dp[u][r] *= pv;
+          const float pv = __builtin_amdgcn_exp2f(sc[r]);
+          sc[r] = pv;
+          dp[r] *= pv;
         }
       } else {
         const int kpos = krow + p.k_off;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float pv = __builtin_amdgcn_exp2f(sc[u][r]);
+          float pv = __builtin_amdgcn_exp2f(sc[r]);
           const int q = qb + 32 * u + acc_row(r, lh);
           if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))))) pv = 0.0f;
-          sc[u][r] = pv;
-          dp[u][r] *= pv;
+          sc[r] = pv;
+          dp[r] *= pv;
         }
       }
-    }
-    // phase 3: dV^T += dO^T P, dK^T += Q'^T dS
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
+      FK_ST(2)
+      // dV^T += dO^T P, dK^T += Q'^T dS
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         Frag<T> pf, df;
-        frag_from_acc<T>(pf, sc[u], s);
-        frag_from_acc<T>(df, dp[u], s);
+        frag_from_acc<T>(pf, sc, s);
+        frag_from_acc<T>(df, dp, s);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           Frag<T> gtf, qtf;
@@ -1344,13 +1412,22 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p) {
           mma32<T>(dk[dt], qtf, df);
         }
       }
-    if (t + 1 < ntiles) store_stats(SLOT ^ 1);
-    dma_wait_barrier();
+      FK_ST(3)
+      if constexpr (FK_DMA_POS == 1) { if (u == 0) { request(); FK_ST(0) } }
+    }
+    if constexpr (FK_DMA_POS == 2) { request(); FK_ST(0) }
+    if (t + 1 < ntiles) store_stats((SLOT + 1) % NS);
+    FK_ST(4)
+    // tile t+1 (and wave 0's statistics of it) has landed, the request for tile t+2 stays in flight across the barrier
+    if (t + 2 < ntiles) wait_next(); else dma_wait_barrier();
+    FK_ST(5)
   };
-  for (int t = 0; t < ntiles; t += 2) {
+  for (int t = 0; t < ntiles; t += 3) {
     tile_step(std::integral_constant<int, 0>{}, t);
     if (t + 1 < ntiles) tile_step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < ntiles) tile_step(std::integral_constant<int, 2>{}, t + 2);
   }
+  FK_ST(6)
   // dK = scale * dS^T Q = ln(2) * dS^T Q'   (Q' = scale * log2(e) * Q)
   T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
   T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
@@ -1359,6 +1436,8 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p) {
   else
     store_rows_T<T, D>(dKp, p.k_rs, krow, k_ok, dk, LN2, lh);
   store_rows_T<T, D>(dVp, p.v_rs, krow, k_ok, dv, 1.0f, lh);
+  FK_ST(7)
+  FK_ST_FLUSH(0)
 }
 
 // ------------------------------------------------------------------------------------------------- host
@@ -1366,20 +1445,31 @@ template <typename T, int D> size_t fwd_lds() {
   return Img<T, D>::SWZ ? (size_t)3 * 2 * BKV * 128 : (size_t)2 * BKV * (AT<T, D>::RSTRIDE + AT<T, D>::VSTRIDE);
 }
 template <typename T, int D> size_t dq_lds() { return 4 * BKV * AT<T, D>::RSTRIDE; }
+constexpr size_t DQ_PS_LDS = 6 * BKV * 128, DKDV_PS_LDS = 6 * 64 * 128 + 3 * 2 * 64 * sizeof(float);
 template <typename T, int D> size_t dkdv_lds() { return 4 * 64 * AT<T, D>::RSTRIDE + 4 * 64 * sizeof(float); }
 
 template <typename K> void allow_lds(K kernel, size_t bytes) {
   if (bytes > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+#ifndef FK_FWD_NW
+#define FK_FWD_NW 8
+#endif
+#ifndef FK_DQ_NW
+#define FK_DQ_NW 4
+#endif
+#ifndef FK_DKDV_NW
+#define FK_DKDV_NW 4
+#endif
 template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
   constexpr int NW = Img<T, D>::SWZ ? 8 : 4;
   if constexpr (Img<T, D>::SWZ) {
     if (a.flags & FK_ATTN_Q_PRESCALED) {
-      dim3 grid((unsigned)(((a.Nq + NW * 32 - 1) / (NW * 32)) * a.H * a.B));
+      constexpr int NWF = FK_FWD_NW;
+      dim3 grid((unsigned)(((a.Nq + NWF * 32 - 1) / (NWF * 32)) * a.H * a.B));
       const size_t lds = fwd_lds<T, D>();
-      allow_lds(attn_fwd_ps_kernel<NW>, lds);
-      hipLaunchKernelGGL((attn_fwd_ps_kernel<NW>), grid, dim3(NW * 64), lds, s, a);
+      allow_lds(attn_fwd_ps_kernel<NWF>, lds);
+      hipLaunchKernelGGL((attn_fwd_ps_kernel<NWF>), grid, dim3(NWF * 64), lds, s, a);
       return 0;
     }
   }
@@ -1398,10 +1488,12 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
   dim3 gq((unsigned)(((a.Nq + BQ - 1) / BQ) * a.H * a.B));
   if constexpr (Img<T, D>::SWZ) {
     if (a.flags & FK_ATTN_Q_PRESCALED) {
-      allow_lds(attn_bwd_dkdv_ps_kernel, lds_kv);
-      allow_lds(attn_bwd_dq_ps_kernel, lds_q);
-      hipLaunchKernelGGL(attn_bwd_dq_ps_kernel, gq, dim3(NT), lds_q, s, a);
-      hipLaunchKernelGGL(attn_bwd_dkdv_ps_kernel, gk, dim3(NT), lds_kv, s, a);
+      constexpr int NWQ = FK_DQ_NW, NWK = FK_DKDV_NW;
+      dim3 gq2((unsigned)(((a.Nq + NWQ * 32 - 1) / (NWQ * 32)) * a.H * a.B)), gk2((unsigned)(((a.Nk + NWK * 32 - 1) / (NWK * 32)) * a.H * a.B));
+      allow_lds(attn_bwd_dkdv_ps_kernel<NWK>, DKDV_PS_LDS);
+      allow_lds(attn_bwd_dq_ps_kernel<NWQ>, DQ_PS_LDS);
+      hipLaunchKernelGGL(attn_bwd_dq_ps_kernel<NWQ>, gq2, dim3(NWQ * 64), DQ_PS_LDS, s, a);
+      hipLaunchKernelGGL(attn_bwd_dkdv_ps_kernel<NWK>, gk2, dim3(NWK * 64), DKDV_PS_LDS, s, a);
       return 0;
     }
   }
@@ -1455,6 +1547,15 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
 }  // namespace
 
 extern "C" {
+
+#ifdef FK_STAMP
+int fk_debug_stamps(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(fk_stamp_acc), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(fk_stamp_acc), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
                 int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,

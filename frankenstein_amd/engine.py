@@ -125,10 +125,11 @@ def norm_bwd(dh: Tensor, x2: Tensor, ln_w: Tensor, ln_b: Optional[Tensor], mean:
 class _Shadow:
     """One compute-dtype weight copy.  `jobs` are the fk_cast_pack_rows calls that fill `tensor` from the masters
     (src, dst view, transpose, rblk, rstride, roff); `params` are weak references (a shadow dies with its model)."""
-    __slots__ = ("stamp", "tensor", "jobs", "params", "dtype", "ptrs")
+    __slots__ = ("stamp", "tensor", "jobs", "params", "dtype", "ptrs", "repack")
 
     def __init__(self):
         self.stamp, self.tensor, self.jobs, self.params, self.dtype, self.ptrs = None, None, [], (), None, ()
+        self.repack = None       # shadows whose layout is not a cast_pack job (convolution weights): callable that refills `tensor` in place
 
     def alive(self) -> bool:
         """masters still exist and still live where the pack jobs read them (ParamArena moves parameter storage)"""
@@ -242,6 +243,12 @@ def refresh_shadows(params: Sequence[Tensor]) -> None:
     ids = {id(p) for p in params}
     for k in [k for k, e in _SHADOWS.items() if not e.alive()]:
         del _SHADOWS[k]
+    # shadows with their own in-place re-pack (convolution weights): refreshed here too, so that a captured graph, which keeps
+    # reading the shadow's storage, sees every optimizer step (they used to be rebuilt lazily into NEW storage by the eager forward only)
+    for e in _SHADOWS.values():
+        if e.repack is not None and e.tensor is not None and e.dtype == _COMPUTE_DTYPE and all(id(r()) in ids for r in e.params):
+            e.repack()
+            e.stamp = e.current_stamp()
     ents = [e for e in _SHADOWS.values()
             if e.jobs and e.dtype == _COMPUTE_DTYPE and e.tensor.is_cuda and all(id(r()) in ids for r in e.params)]
     if not ents:
@@ -691,15 +698,23 @@ def _conv_shadow(w: Tensor, mode: str, transpose: bool) -> Tensor:
     stamp = ent.current_stamp()
     if ent.stamp == stamp:
         return ent.tensor
-    wd = w.detach()
-    if mode == "conv":
-        g = wd.permute(0, 2, 1).reshape(wd.shape[0], -1)
-    else:
-        cin, cout, k2 = wd.shape
-        s_ = k2 // 2
-        g = torch.cat([wd[:, :, s_:].permute(2, 1, 0), wd[:, :, :s_].permute(2, 1, 0)], dim=2).reshape(s_ * cout, 2 * cin)
-    g = (g.t() if transpose else g).contiguous()
-    ent.tensor = g if _COMPUTE_DTYPE == torch.float32 else K.cast(g, _COMPUTE_DTYPE)
+    wref = ent.params[0]
+
+    def pack():
+        wd = wref().detach()
+        if mode == "conv":
+            g = wd.permute(0, 2, 1).reshape(wd.shape[0], -1)
+        else:
+            cin, cout, k2 = wd.shape
+            s_ = k2 // 2
+            g = torch.cat([wd[:, :, s_:].permute(2, 1, 0), wd[:, :, :s_].permute(2, 1, 0)], dim=2).reshape(s_ * cout, 2 * cin)
+        g = g.t() if transpose else g
+        if ent.tensor is None:
+            ent.tensor = torch.empty(g.shape, dtype=_COMPUTE_DTYPE, device=wd.device)
+        ent.tensor.copy_(g)                 # in place: the storage a captured GEMM reads stays the same across optimizer steps
+
+    ent.repack = pack
+    pack()
     ent.stamp = stamp
     return ent.tensor
 

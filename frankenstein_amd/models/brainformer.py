@@ -77,12 +77,10 @@ def build_complex_rope_cache(dim: int, seq_len: int, theta: float) -> torch.Tens
     return cache
 
 
-_MASKS: dict = {}
-
-
 def register_mask(t: torch.Tensor, mask: Mask) -> None:
-    """Tell the attention path that boolean tensor ``t`` IS the analytic mask ``mask``."""
-    _MASKS[(t.data_ptr(), tuple(t.shape))] = mask
+    """Tell the attention path that boolean tensor ``t`` IS the analytic mask ``mask``.  The tag lives on the tensor object itself
+    (no address-keyed registry: a freed mask's address can be recycled by an unrelated tensor of the same shape)."""
+    t._fk_mask = mask
 
 
 def resolve_mask(attn_mask, t_q: int, t_k: int) -> Mask:
@@ -90,7 +88,7 @@ def resolve_mask(attn_mask, t_q: int, t_k: int) -> Mask:
         return NO_MASK
     if isinstance(attn_mask, Mask):
         return attn_mask
-    m = _MASKS.get((attn_mask.data_ptr(), tuple(attn_mask.shape)))
+    m = getattr(attn_mask, "_fk_mask", None)
     if m is None:
         raise NotImplementedError(
             "frankenstein_amd attention takes analytic masks (None, causal, block-causal built by "
@@ -319,9 +317,27 @@ class Encoder(nn.Module):
         self.space_embedding = nn.Parameter(torch.randn(1, config.n_electrodes, config.dim), requires_grad=True)
         self.precompute_rope_cash = build_complex_rope_cache(dim=config.head_dim, seq_len=self.block_size,
                                                              theta=config.rope_theta)
-        self.register_buffer('attn_mask', build_advanced_causal_mask(block_size=self.block_size,
-                                                                     tok_per_time=self.n_electrodes))
+        # The reference registers the [N, N] boolean mask as a buffer (models/brainformer.py:298): 37.7 MB at N = 6144 that no kernel
+        # here reads.  It is therefore built lazily, on the host, only when somebody asks for `.attn_mask` or for a state dict (whose
+        # `attn_mask` key is kept for safetensors load_model / save_model compatibility); the forward uses the analytic form.
+        self._attn_mask_host = None
+        self._register_state_dict_hook(Encoder._state_dict_mask_hook)
+        self._register_load_state_dict_pre_hook(Encoder._load_state_dict_mask_hook)
         print("Encoder: number of parameters: %.2fM" % (self.get_num_params() / 1e6,))
+
+    @property
+    def attn_mask(self) -> torch.Tensor:
+        if self._attn_mask_host is None:
+            self._attn_mask_host = build_advanced_causal_mask(block_size=self.block_size, tok_per_time=self.n_electrodes)
+        return self._attn_mask_host
+
+    @staticmethod
+    def _state_dict_mask_hook(module, state_dict, prefix, local_metadata):
+        state_dict[prefix + "attn_mask"] = module.attn_mask
+
+    @staticmethod
+    def _load_state_dict_mask_hook(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        state_dict.pop(prefix + "attn_mask", None)          # a function of the config, not a learned value
 
     @property
     def dtype(self) -> torch.dtype:
@@ -356,10 +372,11 @@ class Encoder(nn.Module):
         assert x.shape[2] == self.n_electrodes and x.shape[1] % self.patch_size == 0
         h = E.PatchEmbed.apply(x, self.transformer.emb.weight, self.transformer.emb.bias, self.space_embedding,
                                self.patch_size)
-        register_mask(self.attn_mask, Mask(MASK_BLOCK_CAUSAL, self.n_electrodes))   # survives .to(device)
+        T = h.shape[1]
+        mask = Mask(MASK_BLOCK_CAUSAL, self.n_electrodes).sliced(self.block_size, self.block_size, T, T)   # attn_mask[-T:, -T:]
         rope = self.rope_cache
         for block in self.transformer.h:
-            h = block(h, attn_mask=self.attn_mask, rope=rope, kv_cache=kv_cache)
+            h = block(h, attn_mask=mask, rope=rope, kv_cache=kv_cache)
         return self.transformer.ln_f(h)
 
 
@@ -441,7 +458,8 @@ class MAE(nn.Module):
 def _mae_get_sub_att_matrix(self, attn_mask, unmasked_indices):
     """Dense form of the gathered block-causal sub-mask, [b, 1, n, n] bool (models/brainformer.py:392-413).  Kept for API parity and
     for checking: the forward itself passes the same mask analytically (kernels.Mask.from_token_ids), never as a tensor."""
-    sub = attn_mask[unmasked_indices[:, :, None], unmasked_indices[:, None, :]]
+    am = attn_mask.to(unmasked_indices.device)
+    sub = am[unmasked_indices[:, :, None], unmasked_indices[:, None, :]]
     return sub[:, None]
 
 

@@ -139,11 +139,13 @@ class GradSync:
     1/world is folded into the optimizer kernel) as soon as every parameter of the bucket has its gradient,
     asynchronously on the process group's communication stream, so the exchange overlaps the remaining backward."""
 
-    def __init__(self, arena: ParamArena, group=None, bucket_bytes: int = 8 << 20):
+    def __init__(self, arena: ParamArena, group=None, bucket_bytes: int = 8 << 20, always: bool = False):
         import torch.distributed as dist
         self.dist, self.group, self.arena = dist, group, arena
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.enabled = True
+        # always=True: issue the collectives also in a one-rank group (identity) — how the RCCL path is rehearsed on a one-GPU box
+        self.active = self.world > 1 or (always and dist.is_available() and dist.is_initialized())
         self.buckets: List[tuple] = []           # (start, end, n_params)
         self.bucket_of: List[int] = []
         cap = max(1, bucket_bytes // 4)
@@ -159,10 +161,20 @@ class GradSync:
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._works = []
-        if self.world > 1:
+        if self.active:
+            # replicas start from rank 0's parameters: what wrapping the model in DDP does in the reference
+            # (accelerator.prepare, utils/train_utils.py:122) — identical seeds are not relied upon
+            self.broadcast_parameters()
             for i, p in enumerate(arena.params):
                 hook = self._make_hook(self.bucket_of[i])
                 p.register_post_accumulate_grad_hook(hook)     # also fires when engine.wgrad wrote the gradient itself
+
+    def broadcast_parameters(self, src: int = 0):
+        """Every rank takes the master parameters of group rank `src` (one collective over the flat arena)."""
+        if self.active:
+            gsrc = self.dist.get_global_rank(self.group, src) if self.group is not None else src
+            self.dist.broadcast(self.arena.flat, src=gsrc, group=self.group)
+            E.bump_weight_epoch()
 
     def _make_hook(self, b: int):
         def hook(_param):
@@ -190,7 +202,7 @@ class GradSync:
     def finish(self) -> float:
         """Launch whatever has not gone out (unused parameters), wait for all buckets; returns the factor that turns
         the summed gradient into the DDP mean."""
-        if self.world > 1 and self.enabled:
+        if self.active and self.enabled:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)
@@ -213,10 +225,15 @@ class FusedAdamW:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999),
                  eps: float = 1e-8, grad_clip: Optional[float] = None, group=None, bucket_bytes: int = 8 << 20,
-                 overlap_wgrad: Optional[bool] = None):
+                 overlap_wgrad: Optional[bool] = None, sync_always: bool = False):
         self.arena = ParamArena(model)
+        env_on = os.environ.get("FK_WGRAD_STREAM", "0") == "1"
         if overlap_wgrad is None:
-            overlap_wgrad = os.environ.get("FK_WGRAD_STREAM", "0") == "1"     # see engine.py: off by default
+            overlap_wgrad = env_on                                             # see engine.py: off by default
+        if overlap_wgrad and not env_on:
+            # EXPERIMENTAL: with the weight-gradient side stream on, gradients were observed to differ run to run on ragged shapes
+            # (DESIGN.md §5.1); the mode is not part of the supported surface until that is explained
+            raise RuntimeError("overlap_wgrad is experimental (run-to-run differences, DESIGN.md): set FK_WGRAD_STREAM=1 to opt in")
         if overlap_wgrad and self.arena.flat.is_cuda and E.wgrad_stream() is None:
             E.enable_wgrad_stream(True)
         self.m = torch.zeros_like(self.arena.flat)
@@ -224,14 +241,21 @@ class FusedAdamW:
         self.param_groups = [dict(params=self.arena.params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)]
         self.grad_clip = grad_clip
         self.t = 0
-        self.sync = GradSync(self.arena, group, bucket_bytes)
+        self.sync = GradSync(self.arena, group, bucket_bytes, always=sync_always)
 
     def zero_grad(self, set_to_none: bool = True):
         self.arena.grad.zero_()
         self.arena.rebind_grads()
 
     def step(self):
+        """Updates EVERY arena parameter (weight decay and moment decay included), also one that received no gradient this
+        step — torch.optim.AdamW skips those; every model in this repository uses all its parameters every step."""
         g = self.param_groups[0]
+        a = self.arena
+        p0, p1 = a.params[0], a.params[-1]
+        if p0.data_ptr() != a.flat.data_ptr() + 4 * a.offsets[0] or p1.data_ptr() != a.flat.data_ptr() + 4 * a.offsets[-1]:
+            raise RuntimeError("parameters no longer live in the optimizer's arena (model.to() / .float() after constructing "
+                               "FusedAdamW?): build the optimizer after the model is on its final device")
         self.arena.rebind_grads()
         scale = self.sync.finish()
         side = E.wgrad_stream()
@@ -245,6 +269,15 @@ class FusedAdamW:
 
     def state_dict(self):
         return dict(t=self.t, m=self.m, v=self.v, param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        """Resume: step count, both moment arenas and the hyper-parameters (the parameters themselves travel with the model)."""
+        assert sd["m"].numel() == self.m.numel() and sd["v"].numel() == self.v.numel(), "optimizer state of another model"
+        self.t = int(sd["t"])
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
+        for g, src in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in src.items() if k != 'params'})
 
 
 # ------------------------------------------------------------------------------------------------ the step

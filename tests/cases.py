@@ -85,6 +85,36 @@ def summarize_rows(named):
     return names, np.array(rows)
 
 
+def sample_index(n: int, k: int = 256) -> np.ndarray:
+    """k evenly spaced flat indices of an n-element tensor (all of them when n <= k): the gradient samples stored for the
+    full-size fixtures, whose complete gradients would be tens of MB."""
+    return np.arange(n) if n <= k else (np.arange(k, dtype=np.int64) * n) // k
+
+
+def sample_rows(named, k: int = 256):
+    """name -> float64 [k] sample of the flattened tensor (zero padded below k elements)."""
+    names, rows = [], []
+    for key, v in named.items():
+        a = v.detach().double().flatten().numpy()
+        r = np.zeros(k)
+        idx = sample_index(a.size, k)
+        r[: idx.size] = a[idx]
+        names.append(key)
+        rows.append(r)
+    return names, np.array(rows)
+
+
+def cfg2_ce(B=1):
+    """cfg2's CE-head variant (notebook class, n_output_tokens=25, output_dim=50257)."""
+    enc = R.mae_config(window_size=600, n_electrodes=256, patch_size=25, dim=384, n_layers=6, head_dim=64,
+                       hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    cfg = R.perceiver_config(enc, n_output_tokens=25, output_dim=50257, dim=384, n_layers=2, head_dim=64,
+                             hidden_dim=768, n_heads=6, n_kv_heads=6)
+    x = t(synth.make_inputs(B, 600, 256))
+    tok = t(synth.make_tokens(B, 25))
+    return cfg, x, tok
+
+
 def mae_small():
     cfg = R.mae_config(window_size=32, n_electrodes=16, patch_size=4, dim=64, n_layers=2, head_dim=16, hidden_dim=128,
                        n_heads=4, n_kv_heads=4, n_dec_layers=2, decoder_dim=64)

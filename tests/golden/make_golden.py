@@ -275,6 +275,28 @@ def main():
     gn, gr = summarize(grads_of(m))
     save("cfg2_b1", loss=np.array(float(loss)), pred=pred.detach().numpy(),
          enc_rows=ctx[0, [0, 1, 255, 256, 3071, 6143]].numpy(), grad_names=gn, grad_rows=gr)
+    # evenly spaced 256-element samples of every gradient of the same run (the full gradients are 81 MB): what the bf16 parity test at
+    # the benchmarked shape computes its per-parameter cosine from
+    from tests import cases as TC
+    sn, sr = TC.sample_rows(grads_of(m))
+    save("cfg2_b1_samples", loss=np.array(float(loss)), grad_names=np.array(sn), grad_samples=sr,
+         enc_samples=ctx[0].double().flatten().numpy()[TC.sample_index(ctx[0].numel(), 4096)])
+
+    # ---- cfg2's CE-head variant at B=1 (notebook CE BrainFormer, n_output_tokens=25, output_dim=50257)
+    cfg = bf.Config(encoder=enc, n_output_tokens=25, output_dim=50257, dim=384, n_layers=2, head_dim=64,
+                    hidden_dim=768, n_heads=6, n_kv_heads=6)
+    m = BrainFormerCE(cfg).float()
+    load_synth(m)
+    tok = torch.from_numpy(synth.make_tokens(1, 25))
+    loss, logits = m(x, tok)
+    loss.backward()
+    lg = logits.detach()
+    gn, gr = summarize(grads_of(m))
+    sn, sr = TC.sample_rows(grads_of(m))
+    save("cfg2_b1_ce", loss=np.array(float(loss)), targets=tok.numpy(), logits_head=lg[:, :, :64].numpy(),
+         logits_tail=lg[:, :, -33:].numpy(), logits_lse=torch.logsumexp(lg, -1).numpy(), logits_argmax=lg.argmax(-1).numpy(),
+         logits_at_target=lg[0].gather(-1, tok[0].clamp(min=0)[:, None])[:, 0].numpy(),
+         grad_names=gn, grad_rows=gr, grad_samples=sr)
 
     # ---- mae_small: brainformer.MAE (models/brainformer.py:354-486); the random index sets are recorded as inputs
     enc = bf.MAEConfig(window_size=32, n_electrodes=16, patch_size=4, dim=64, n_layers=2, head_dim=16, hidden_dim=128,

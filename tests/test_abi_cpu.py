@@ -56,6 +56,42 @@ def test_argument_validation_needs_no_gpu(built):
     assert rc == -1
 
 
+def test_integration_snippet_matches_the_binding():
+    """The ctypes example a maintainer would copy from INTEGRATION.md: its argtypes equal _lib.SIGNATURES["fk_attn_fwd"] and the call
+    passes exactly that many arguments (the round-1 version of the snippet had drifted from the header)."""
+    import ctypes
+    from frankenstein_amd import _lib
+    txt = (ROOT / "INTEGRATION.md").read_text()
+    snippet = txt[txt.index("```python\n# models/brainformer.py"):]
+    snippet = snippet[: snippet.index("```", 10)]
+    line = next(l for l in snippet.splitlines() if l.startswith("_fk.fk_attn_fwd.argtypes"))
+    env = {"ctypes": ctypes, "I64": ctypes.c_int64, "P": ctypes.c_void_p, "INT": ctypes.c_int, "F32": ctypes.c_float}
+    argtypes = eval(line.split("=", 1)[1], env)
+    assert argtypes == _lib.SIGNATURES["fk_attn_fwd"][1]
+    call = snippet[snippet.index("_fk.fk_attn_fwd(q.data_ptr()"):]
+    call = call[call.index("(") + 1: call.index("if rc:")]
+    call = re.sub(r"#.*", "", call)
+    depth, nargs, cur = 0, 0, ""
+    for ch in call:
+        if ch in "([":
+            depth += 1
+        if ch in ")]":
+            if depth == 0:
+                break
+            depth -= 1
+        if ch == "," and depth == 0:
+            nargs += 1
+            cur = ""
+        else:
+            cur += ch
+    nargs += 1 if cur.strip() else 0
+    assert nargs == len(argtypes), (nargs, len(argtypes))
+    # and the header's prototype has the same number of parameters
+    hdr = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "franken_hip.h").read_text(), flags=re.S)
+    proto = re.search(r"int fk_attn_fwd\((.*?)\);", hdr, flags=re.S).group(1)
+    assert len(proto.split(",")) == len(argtypes)
+
+
 def test_missing_library_is_loud(monkeypatch, tmp_path):
     from frankenstein_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -41,16 +41,19 @@ def _batch(B):
     return torch.from_numpy(synth.make_inputs(B, 32, 16)).cuda(), torch.from_numpy(synth.make_motion_targets(B, 8, 12)).cuda()
 
 
-def _worker(rank, world, port, out, overlap=False):
+def _worker(rank, world, port, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from frankenstein_amd.utils import train_utils as tu
     m = _build()
+    if rank != 0:                           # replicas that did NOT start identical: the optimizer's rank-0 broadcast has to fix it
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.add_(0.01 * rank)
     cfg = tu.TrainConfig(mixed_precision=False, use_scheduler=False, learning_rate=1e-3)
-    opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=cfg.weight_decay, grad_clip=cfg.grad_clip, bucket_bytes=64 << 10,
-                        overlap_wgrad=overlap)
+    opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=cfg.weight_decay, grad_clip=cfg.grad_clip, bucket_bytes=64 << 10)
     assert opt.sync.world == world and len(opt.sync.buckets) > 1
     x, y = _batch(4)
     for step in range(2):
@@ -61,12 +64,11 @@ def _worker(rank, world, port, out, overlap=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True], ids=["one-stream", "wgrad-side-stream"])
-def test_two_ranks_equal_one_rank_full_batch(overlap):
+def test_two_ranks_equal_one_rank_full_batch():
     import torch.multiprocessing as mp
     world = 2
     out = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), out, overlap), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert len(out) == world
     np.testing.assert_array_equal(out[0], out[1])            # replicas stay bit-identical
     # single process, full batch (L1 loss is a mean over equal-sized shards -> mean of shard gradients == full gradient)
@@ -81,5 +83,48 @@ def test_two_ranks_equal_one_rank_full_batch(overlap):
     # Adam turns rounding-level gradient differences of (near-)zero-gradient entries into +-lr updates: compare robustly
     diff = np.abs(out[0] - ref)
     assert np.quantile(diff, 0.99) < 2e-5 and diff.max() < 5e-3, (np.quantile(diff, 0.99), diff.max())
+    import frankenstein_amd as fa
+    fa.set_compute_dtype("bf16")
+
+
+def _rccl_worker(rank, port, out):
+    """one rank, backend "nccl" (= RCCL): communicator creation, the rank-0 broadcast of the parameter arena and the bucketed
+    all-reduces issued from the autograd hooks all run through RCCL (a one-rank group, so each collective is the identity)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from frankenstein_amd.utils import train_utils as tu
+    m = _build()
+    cfg = tu.TrainConfig(mixed_precision=False, use_scheduler=False, learning_rate=1e-3)
+    opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=cfg.weight_decay, grad_clip=cfg.grad_clip, bucket_bytes=64 << 10, sync_always=True)
+    assert opt.sync.active and opt.sync.world == 1 and len(opt.sync.buckets) > 1
+    launched = []
+    orig = opt.sync._launch
+    opt.sync._launch = lambda b: (launched.append(b), orig(b))[1]
+    x, y = _batch(4)
+    for step in range(2):
+        tu.train_step(m, (x, y, None), opt, step, cfg)
+    torch.cuda.synchronize()
+    out["flat"] = opt.arena.flat.detach().cpu().numpy()
+    out["launched"] = len(launched)
+    out["nbuckets"] = len(opt.sync.buckets)
+    out["rccl"] = ".".join(map(str, torch.cuda.nccl.version()))
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group_runs_the_collective_path():
+    import torch.multiprocessing as mp
+    out = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert out["launched"] == 2 * out["nbuckets"] and out["rccl"]
+    from frankenstein_amd.utils import train_utils as tu
+    m = _build()
+    cfg = tu.TrainConfig(mixed_precision=False, use_scheduler=False, learning_rate=1e-3)
+    opt = tu.FusedAdamW(m, lr=1e-3, weight_decay=cfg.weight_decay, grad_clip=cfg.grad_clip)
+    x, y = _batch(4)
+    for step in range(2):
+        tu.train_step(m, (x, y, None), opt, step, cfg)
+    np.testing.assert_array_equal(out["flat"], opt.arena.flat.detach().cpu().numpy())     # identity collectives: same bits
     import frankenstein_amd as fa
     fa.set_compute_dtype("bf16")

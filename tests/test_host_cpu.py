@@ -226,3 +226,46 @@ def test_wer_known_answers():
         wer(["a"], ["a", "b"])
     with pytest.raises(ValueError):
         wer([""], ["a"])
+
+
+def test_gpt_init_weights_statistics():
+    """GPT._init_weights + the c_proj rescale (models/gpt2_model.py:141-145,170-176 of the reference): Linear / Embedding weights
+    N(0, 0.02), residual projections N(0, 0.02 / sqrt(2 L)), zero biases, lm_head tied to wte."""
+    import math
+    from frankenstein_amd.models import gpt2_model as g2
+    torch.manual_seed(0)
+    L = 3
+    g = g2.GPT(g2.GPTConfig(block_size=64, vocab_size=1024, n_layer=L, n_head=4, n_embd=256, dropout=0.0, bias=True))
+    assert g.lm_head.weight is g.transformer.wte.weight
+    for name, p in g.named_parameters():
+        if name.endswith("bias"):
+            assert float(p.abs().max()) == 0.0, name
+        elif "ln_" in name:
+            assert float((p - 1).abs().max()) == 0.0, name
+        else:
+            want = 0.02 / math.sqrt(2 * L) if name.endswith("c_proj.weight") else 0.02
+            n = p.numel()
+            # std of n normal samples has relative standard error 1/sqrt(2n): 5 sigma bounds
+            assert abs(float(p.std()) / want - 1.0) < 5.0 / math.sqrt(2 * n), (name, float(p.std()), want)
+            assert abs(float(p.mean())) < 5.0 * want / math.sqrt(n), (name, float(p.mean()))
+
+
+def test_bench_self_launch_dry_run_world2():
+    """`python bench.py --gpus 2` without a launcher starts torch.distributed.run itself (child processes; gloo rendezvous on
+    127.0.0.1), rank 0 prints the one JSON line, and without GPUs the real run refuses with a clear message instead of an assert."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] and out["n_gpus"] == 2 and out["world"] == 2 and out["steps"] == 3 and out["max_rank_time_s"] == 0.002
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "AssertionError" not in r.stderr

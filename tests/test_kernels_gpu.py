@@ -300,7 +300,7 @@ def test_attention_prescaled_q(K, case):
     dkv = torch.empty_like(kvd)
     dk, dv = dkv[..., : H * D].unflatten(-1, (H, D)), dkv[..., H * D:].unflatten(-1, (H, D))
     K.attn_bwd(qd, kd, vd, o, dev(do, dtype), lse, dq, dk, dv, m, q_prescaled=True)
-    close(dq, qr.grad, dtype, atol16=4e-2)
+    close(dq, qr.grad, dtype, atol16=4e-2 * max(1.0, float(qr.grad.abs().max()) / 4))       # (the spike case has |dq|, |dk| >> 1)
     close(dk, kr.grad, dtype, atol16=4e-2 * max(1.0, float(kr.grad.abs().max()) / 4))
     close(dv, vr.grad, dtype, atol16=4e-2)
     # the two forms of the same problem agree with each other at bf16 rounding level

@@ -261,6 +261,89 @@ def test_cfg2_b1_fp32(golden):
     check_grad_rows(m, z, rtol=5e-3, atol=5e-4)
 
 
+def _cosines(model, z):
+    """per-parameter cosine between this model's gradients and the reference's, on the fixture's evenly spaced samples"""
+    names, rows = C.sample_rows(named_grads(model))
+    want = {str(n): r for n, r in zip(z["grad_names"], z["grad_samples"])}
+    out = {}
+    for n, r in zip(names, rows):
+        w = want[n]
+        den = float(np.linalg.norm(r) * np.linalg.norm(w))
+        out[n] = float(np.dot(r, w) / den) if den > 0 else 1.0
+    return out
+
+
+def test_cfg2_b1_bf16_vs_reference(golden):
+    """The BENCHMARKED precision at the benchmarked shape (6 layers, d = 384, N = 6144 tokens, B = 1) against the reference's own
+    fp32 CPU run: loss within 1e-2 relative, prediction and encoder rows within stated absolute bounds, and every parameter's
+    gradient pointing the reference's way (cosine >= 0.99 on the fixture's samples).  The measured numbers go to
+    gpurun_out/parity_cfg2_bf16.json (committed as profiles/r02_parity_cfg2_bf16.json, reported in bench.py's `parity` block)."""
+    import json
+    import os
+    from frankenstein_amd.models import brainformer as bf
+    z, zs = golden("cfg2_b1"), golden("cfg2_b1_samples")
+    fa.set_compute_dtype("bf16")
+    try:
+        cfgo, x, tgt = C.cfg2(1)
+        m = mk_bf(cfgo, bf.BrainFormer)
+        loss, pred = m(x.cuda(), tgt.cuda())
+        with torch.no_grad():
+            ctx = m.encoder(x.cuda())
+        loss.backward()
+        rel = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+        perr = float((pred.float().cpu().detach() - torch.from_numpy(z["pred"])).abs().max())
+        eerr = float(np.abs(ctx[0, [0, 1, 255, 256, 3071, 6143]].float().cpu().numpy() - z["enc_rows"]).max())
+        escale = float(np.abs(z["enc_rows"]).max())
+        cos = _cosines(m, zs)
+        worst = min(cos, key=cos.get)
+        rec = {"shape": "cfg2 at B=1 (6L d=384 6x64 heads, N=6144), bf16 vs reference fp32 CPU", "loss_rel_err": rel,
+               "pred_max_abs_err": perr, "pred_max_abs": float(np.abs(z["pred"]).max()), "enc_rows_max_abs_err": eerr,
+               "enc_rows_max_abs": escale, "grad_cosine_min": cos[worst], "grad_cosine_min_param": worst,
+               "grad_cosine_median": float(np.median(list(cos.values()))), "n_params": len(cos)}
+        if os.path.isdir("gpurun_out"):
+            json.dump(rec, open("gpurun_out/parity_cfg2_bf16.json", "w"), indent=1)
+        print(rec)
+        assert rel < 1e-2, rec
+        assert perr < 5e-2 and eerr < 0.03 * max(1.0, escale), rec
+        assert cos[worst] >= 0.99, rec
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_cfg2_b1_ce_head(golden, mode):
+    """cfg2's CE-head variant (notebook CE BrainFormer, 25 output tokens, V = 50257) at B = 1 against the reference: fp32 mode to the
+    1e-3 logits criterion with identical argmax, bf16 mode to stated bounds."""
+    from frankenstein_amd.models.notebook_models import BrainFormerCE
+    z = golden("cfg2_b1_ce")
+    fa.set_compute_dtype(mode)
+    try:
+        cfgo, x, tok = C.cfg2_ce(1)
+        assert np.array_equal(tok.numpy(), z["targets"])
+        m = mk_bf(cfgo, BrainFormerCE)
+        loss, logits = m(x.cuda(), tok.cuda())
+        lg = logits.float().detach().cpu()
+        loss.backward()
+        cos = _cosines(m, z)
+        lse = torch.logsumexp(lg, -1).numpy()
+        if mode == "fp32":
+            assert abs(float(loss) - float(z["loss"])) < 1e-4
+            np.testing.assert_allclose(lg[:, :, :64].numpy(), z["logits_head"], atol=1e-3)
+            np.testing.assert_allclose(lg[:, :, -33:].numpy(), z["logits_tail"], atol=1e-3)
+            np.testing.assert_allclose(lse, z["logits_lse"], atol=1e-3)
+            assert np.array_equal(lg.argmax(-1).numpy(), z["logits_argmax"])
+            check_grad_rows(m, z, rtol=5e-3, atol=5e-4)
+            assert min(cos.values()) > 0.9999
+        else:
+            assert abs(float(loss) - float(z["loss"])) / float(z["loss"]) < 1e-2
+            assert float(np.abs(lg[:, :, :64].numpy() - z["logits_head"]).max()) < 5e-2
+            assert float(np.abs(lse - z["logits_lse"]).max()) < 5e-2
+            assert (lg.argmax(-1).numpy() == z["logits_argmax"]).mean() >= 0.9
+            assert min(cos.values()) >= 0.99, min(cos.items(), key=lambda kv: kv[1])
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
 def test_bf16_drift_small():
     """bf16 throughput mode vs the fp32 CPU oracle on the small model: bounded drift, same loss to ~1e-2."""
     from frankenstein_amd.models import brainformer as bf
@@ -466,6 +549,35 @@ def test_soundstream_trains():
     assert g.abs().sum() > 0
 
 
+def test_soundstream_graphed_step_tracks_the_optimizer():
+    """GraphedTrainStep on the convolution stack: the captured conv / transposed-conv GEMMs read GEMM-shaped weight shadows that are
+    not cast_pack jobs; they are now re-packed IN PLACE after every optimizer step, so graph replay and the eager step stay bit-identical
+    (before, the captured kernels kept reading the capture-time weights)."""
+    import frankenstein_amd as fa
+    from frankenstein_amd.models import vq_brain as vq
+    from frankenstein_amd.utils import train_utils as tu
+    fa.set_compute_dtype("bf16")
+    try:
+        x = torch.from_numpy(synth.make_inputs(4, 64, 16)).cuda()
+        tc = tu.TrainConfig(mixed_precision=True, use_scheduler=False, learning_rate=2e-3)
+        runs = []
+        for graphed in (False, True):
+            torch.manual_seed(0)
+            net = vq.SoundStream(C=32, D=16, codebook_size=64, n_electrodes=16).cuda().eval()   # eval: no EMA codebook update (host-free but stateful)
+            opt = tu.FusedAdamW(net, lr=2e-3, weight_decay=0.0)
+            if graphed:
+                step = tu.GraphedTrainStep(net, (x, None, None), opt, tc)
+                losses = [float(step((x, None, None), i)) for i in range(5)]
+            else:
+                losses = [float(tu.train_step(net, (x, None, None), opt, i, tc)) for i in range(5)]
+            runs.append((losses, opt.arena.flat.detach().clone()))
+        assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+        assert torch.equal(runs[0][1], runs[1][1])
+        assert runs[0][0][-1] < runs[0][0][0]
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
 def test_soundstream_notebook_shapes():
     """notebooks_trainer/vq_brain_trainer.ipynb cell 1 smoke: [B, 768, 512] -> quantised [B, 192, 64], reconstruction [B, 768, 512]."""
     import frankenstein_amd as fa
@@ -613,8 +725,16 @@ def test_vq_plus_brainformer_pipeline_bf16():
         fa.set_compute_dtype("fp32")
 
 
-@pytest.mark.parametrize("overlap", [False, True], ids=["one-stream", "wgrad-branch"])
-def test_graphed_train_step_is_bit_identical_to_eager(overlap):
+def test_overlap_wgrad_is_opt_in_only(monkeypatch):
+    """The weight-gradient side stream is experimental (run-to-run differences on ragged shapes): asking for it without
+    the FK_WGRAD_STREAM=1 opt-in is an error, not a silently different numerical mode."""
+    from frankenstein_amd.utils import train_utils as tu
+    monkeypatch.delenv("FK_WGRAD_STREAM", raising=False)
+    with pytest.raises(RuntimeError, match="experimental"):
+        tu.FusedAdamW(torch.nn.Linear(8, 8).cuda(), overlap_wgrad=True)
+
+
+def test_graphed_train_step_is_bit_identical_to_eager(overlap=False):
     """train_utils.GraphedTrainStep (forward + backward replayed from one hipGraph, update eager) against train_step on
     the same seeded batches with a cosine schedule: same losses and same parameters bit for bit after 5 steps; a batch of
     another shape is refused."""

@@ -150,6 +150,35 @@ def test_cfg2_b1(golden):
         np.testing.assert_allclose(r, want[n], rtol=2e-3, atol=2e-4, err_msg=n)
 
 
+def test_cfg2_b1_gradient_samples_and_ce_head(golden):
+    """The two fixtures added for the benchmarked shape: evenly spaced samples of every gradient of the L1-head run, and the
+    CE-head variant (notebook class, 25 output tokens, V = 50257) — the oracle reproduces both."""
+    z = golden("cfg2_b1_samples")
+    cfg, x, tgt = C.cfg2(1)
+    sd = leafify(C.state(R.brainformer_shapes(cfg, "to_motion")))
+    loss, _ = R.brainformer_l1(sd, x, tgt, cfg)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    names, rows = C.sample_rows(grads(loss, sd))
+    want = {str(n): r for n, r in zip(z["grad_names"], z["grad_samples"])}
+    for n, r in zip(names, rows):
+        np.testing.assert_allclose(r, want[n], rtol=2e-3, atol=2e-6, err_msg=n)
+    z = golden("cfg2_b1_ce")
+    cfg, x, tok = C.cfg2_ce(1)
+    assert np.array_equal(tok.numpy(), z["targets"])
+    sd = leafify(C.state(R.brainformer_shapes(cfg, "to_words")))
+    loss, logits = R.brainformer_ce(sd, x, tok, cfg)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    lg = logits.detach()
+    np.testing.assert_allclose(lg[:, :, :64].numpy(), z["logits_head"], atol=1e-4)
+    np.testing.assert_allclose(lg[:, :, -33:].numpy(), z["logits_tail"], atol=1e-4)
+    np.testing.assert_allclose(torch.logsumexp(lg, -1).numpy(), z["logits_lse"], atol=1e-4)
+    assert np.array_equal(lg.argmax(-1).numpy(), z["logits_argmax"])
+    names, rows = C.sample_rows(grads(loss, sd))
+    want = {str(n): r for n, r in zip(z["grad_names"], z["grad_samples"])}
+    for n, r in zip(names, rows):
+        np.testing.assert_allclose(r, want[n], rtol=2e-3, atol=2e-6, err_msg=n)
+
+
 def test_mae_small(golden):
     z = golden("mae_small")
     cfg, x = C.mae_small()
