@@ -1335,9 +1335,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
   auto tile_step = [&](auto SL, int t) {
     constexpr int SLOT = decltype(SL)::value;
     const int qb = qs + t * TQ;
-    // request tile t+2: slot (SLOT + 2) % 3 held tile t-1, which every wave left at the barrier that ended the previous step.  WHERE in the
-    // step the request is issued matters: right after the barrier all waves of the workgroup issue their pieces at once and queue behind
-    // each other in the CU's one vector-memory path (190 cycles per piece measured with -DFK_STAMP)
+    // request tile t+2: slot (SLOT + 2) % 3 held tile t-1, which every wave left at the barrier that ended the previous step (an LDS-DMA
+    // piece costs the issuing wave ~190 cycles, measured with -DFK_STAMP, wherever in the step it is issued)
     auto request = [&]() {
       if (t + 2 < ntiles) {
         dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qb + 2 * TQ, p.Nq, qimg((SLOT + 2) % NS), wave, lane);
@@ -1345,10 +1344,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
       }
       if (t + 1 < ntiles) load_stats(qb + 2 * TQ);      // st_* <- tile t+1 (requested one step ago), nx_* <- tile t+2 (nothing past Nq)
     };
-#ifndef FK_DMA_POS
-#define FK_DMA_POS 0
-#endif
-    if constexpr (FK_DMA_POS == 0) request();
+    request();
     FK_ST(0)
     const char* qt = qimg(SLOT);
     const char* gt = gimg(SLOT);
@@ -1413,9 +1409,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
         }
       }
       FK_ST(3)
-      if constexpr (FK_DMA_POS == 1) { if (u == 0) { request(); FK_ST(0) } }
     }
-    if constexpr (FK_DMA_POS == 2) { request(); FK_ST(0) }
     if (t + 1 < ntiles) store_stats((SLOT + 1) % NS);
     FK_ST(4)
     // tile t+1 (and wave 0's statistics of it) has landed, the request for tile t+2 stays in flight across the barrier
