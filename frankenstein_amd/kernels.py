@@ -454,6 +454,37 @@ def kv_append_(qkv: Tensor, kv: Tensor, pos: Tensor) -> None:
     call("fk_kv_append", qkv.data_ptr(), kv.data_ptr(), pos.data_ptr(), B, d3 // 3, kv.shape[1], fk_dtype(qkv), _stream())
 
 
+class SampleState:
+    """Device-side state of fk_sample_topk: Philox seed, step counter (= column of `out` the next draw goes to), ticket word."""
+
+    def __init__(self, device, seed: Optional[int] = None, step: int = 0):
+        if seed is None:                                   # follows torch.manual_seed like torch.multinomial would
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.seed = torch.tensor([seed], dtype=torch.int64, device=device)
+        self.step = torch.tensor([step], dtype=torch.int64, device=device)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def sample_topk(logits: Tensor, temperature: float, top_k: Optional[int], state: SampleState, cur: Optional[Tensor] = None,
+                out: Optional[Tensor] = None, pos_inc: Optional[Tensor] = None) -> Tensor:
+    """One token per row of fp32 logits [B, V] (row stride >= V): temperature, top-k crop, softmax, multinomial — one launch
+    (models/gpt2_model.py:340-351).  Writes cur [B] int64 (returned), out[:, step] if given, then step += 1 (and pos_inc += 1)."""
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    B, V = logits.shape
+    if cur is None:
+        cur = torch.empty(B, dtype=torch.int64, device=logits.device)
+    assert cur.dtype == torch.int64 and cur.is_contiguous() and cur.numel() == B
+    out_ld = 0
+    if out is not None:
+        assert out.dtype == torch.int64 and out.dim() == 2 and out.shape[0] == B and out.stride(1) == 1
+        out_ld = out.stride(0)
+    if pos_inc is not None:
+        assert pos_inc.dtype == torch.int32 and pos_inc.numel() == 1
+    call("fk_sample_topk", logits.data_ptr(), logits.stride(0), B, V, float(temperature), int(top_k or 0), state.seed.data_ptr(),
+         state.step.data_ptr(), _ptr(pos_inc), cur.data_ptr(), _ptr(out), out_ld, state.ticket.data_ptr(), _stream())
+    return cur
+
+
 def attn_decode(qkv: Tensor, kv: Tensor, pos: Tensor, n_head: int) -> Tensor:
     """one causal query per sample against the cache rows 0..pos[0]: q = qkv[:, :d] -> o [B, d]."""
     B, d3 = qkv.shape

@@ -313,7 +313,14 @@ class GPT(nn.Module):
         return K.gemm_nt(h, E.shadow([self.lm_head.weight], pad_n=(V + 7) // 8 * 8), out_dtype=torch.float32)[:, :V]
 
     @staticmethod
-    def _sample(logits, temperature, top_k):
+    def _sample(logits, temperature, top_k, state=None):
+        """temperature -> top-k crop -> softmax -> multinomial (models/gpt2_model.py:340-351).  On the device this is ONE launch
+        (fk_sample_topk, Philox keyed by a seed drawn from torch's generator); the torch-op form is kept for host tensors."""
+        if logits.is_cuda:
+            lg = logits.float()
+            lg = lg if lg.stride(-1) == 1 else lg.contiguous()
+            st = state if state is not None else K.SampleState(logits.device)
+            return K.sample_topk(lg, temperature, top_k, st).view(-1, 1).clone()
         logits = logits.float() / temperature
         if top_k is not None:
             v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
@@ -333,6 +340,7 @@ class GPT(nn.Module):
         t_ctx = 0 if prefix is None else prefix.shape[1]
         total = t_ctx + t0 + max_new_tokens
         cached = use_cache and total <= self.config.block_size and max_new_tokens > 0
+        state = K.SampleState(idx.device) if idx.is_cuda else None      # one Philox stream per call, seeded from torch's generator
         if use_graph is None:
             use_graph = max_new_tokens >= 64
         if cached:
@@ -349,24 +357,22 @@ class GPT(nn.Module):
                 idx_cond = idx if idx.size(1) <= self.config.block_size else idx[:, -self.config.block_size:]
                 _, lg = self(idx_cond, prefix=prefix)
                 logits = lg[:, -1, :]
-            idx = torch.cat((idx, self._sample(logits, temperature, top_k)), dim=1)
+            idx = torch.cat((idx, self._sample(logits, temperature, top_k, state)), dim=1)
         return idx[0]
 
     @torch.no_grad()
     def _generate_graph(self, idx, logits0, cache, pos0, max_new_tokens, temperature, top_k):
         B, dev = idx.shape[0], idx.device
         out = torch.empty((B, max_new_tokens), dtype=torch.int64, device=dev)
-        cur = self._sample(logits0, temperature, top_k).view(B).contiguous()
-        out[:, 0] = cur
+        cur = torch.empty(B, dtype=torch.int64, device=dev)
+        state = K.SampleState(dev)                       # step counter = the column of `out` the next token goes to
+        lg0 = logits0.float()
+        K.sample_topk(lg0 if lg0.stride(-1) == 1 else lg0.contiguous(), temperature, top_k, state, cur=cur, out=out)
         pos = torch.tensor([pos0], dtype=torch.int32, device=dev)
-        col = torch.ones(1, dtype=torch.int64, device=dev)
 
         def step():
-            nxt = self._sample(self._decode_logits_dev(cur, cache, pos), temperature, top_k)
-            cur.copy_(nxt.view(B))
-            out.index_copy_(1, col, nxt)
-            col.add_(1)
-            pos.add_(1)
+            # the whole sampling tail is one launch: it writes cur / out[:, step] and advances both the step counter and `pos`
+            K.sample_topk(self._decode_logits_dev(cur, cache, pos), temperature, top_k, state, cur=cur, out=out, pos_inc=pos)
 
         n_eager = min(2, max_new_tokens - 1)            # warm-up (allocator, lazy shadows) before the capture
         side = torch.cuda.Stream()

@@ -711,3 +711,46 @@ def test_degenerate_shapes(K, dtype):
     K.attn_bwd(dev(qq, dtype), dev(qq, dtype), dev(qq, dtype), o, torch.ones_like(o), lse, dq, dk, dv, K.Mask(K.MASK_CAUSAL))
     close(dv, torch.ones_like(qq), dtype, atol32=1e-6)
     assert float(dq.abs().max()) < 1e-5 and float(dk.abs().max()) < 1e-5     # softmax over one key is constant
+
+
+def test_sample_topk_on_device(K):
+    """fk_sample_topk = logits / T -> top-k crop (ties kept) -> softmax -> one multinomial draw (models/gpt2_model.py:340-351): the
+    empirical distribution of 40 000 draws matches the exact one, draws never leave the top-k set, top_k = 1 is the argmax, and the
+    device-side step / position counters advance once per launch whatever the number of rows."""
+    B, V, k, T = 3, 1000, 40, 0.8
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(B, 1024, generator=g)[:, :V] * 2.0            # row stride 1024 > V
+    lg = logits.cuda()
+    assert lg.stride(0) == 1024
+    ref = logits / T
+    kth = ref.topk(k, dim=-1).values[:, -1:]
+    probs = torch.softmax(ref.masked_fill(ref < kth, float("-inf")), dim=-1)
+    state = K.SampleState(lg.device, seed=1234)
+    pos = torch.tensor([7], dtype=torch.int32, device="cuda")
+    n = 40000
+    out = torch.empty((B, n), dtype=torch.int64, device="cuda")
+    cur = torch.empty(B, dtype=torch.int64, device="cuda")
+    for _ in range(n):
+        K.sample_topk(lg, T, k, state, cur=cur, out=out, pos_inc=pos)
+    assert int(state.step) == n and int(pos) == 7 + n and int(state.ticket) == 0
+    assert torch.equal(out[:, -1], cur)
+    o = out.cpu()
+    for b in range(B):
+        cnt = torch.bincount(o[b], minlength=V).double()
+        assert int((cnt[probs[b] == 0] > 0).sum()) == 0                 # never outside the top-k set
+        tv = 0.5 * float((cnt / n - probs[b].double()).abs().sum())
+        assert tv < 0.03, tv                                            # total variation; sampling noise at n = 40 000, k = 40 is ~0.012
+    # different rows draw independently (same step, different Philox counter)
+    assert float((o[0] == o[1]).double().mean()) < 0.2
+    # reproducible from the seed
+    st2 = K.SampleState(lg.device, seed=1234)
+    again = torch.stack([K.sample_topk(lg, T, k, st2).clone() for _ in range(50)], 1)
+    assert torch.equal(again.cpu(), o[:, :50])
+    # greedy and untruncated forms
+    st3 = K.SampleState(lg.device, seed=5)
+    assert torch.equal(K.sample_topk(lg, 1.0, 1, st3).cpu(), logits.argmax(-1))
+    full = torch.stack([K.sample_topk(lg, 1.0, None, st3).clone() for _ in range(4000)], 1).cpu()
+    pf = torch.softmax(logits, -1)
+    for b in range(B):
+        cnt = torch.bincount(full[b], minlength=V).double()
+        assert 0.5 * float((cnt / 4000 - pf[b].double()).abs().sum()) < 0.25
