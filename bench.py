@@ -97,9 +97,9 @@ def cpu_baseline(steps=2):
 
 def mfma_util_pmc():
     """MFMA-pipe busy fraction of the whole step and of the roofline kernels from the committed rocprofv3 counter pass
-    (profiles/r01_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); None if absent."""
+    (profiles/r02_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); None if absent."""
     try:
-        pm = json.load(open(ROOT / "profiles" / "r01_pmc_mfma_util.json"))
+        pm = json.load(open(ROOT / "profiles" / "r02_pmc_mfma_util.json"))
         ks = pm["kernels"]
         pick = lambda frag: next((round(v["mfma_util_pct"], 1) for k, v in ks.items() if frag in k), None)
         return {"whole_step_pct": round(pm["whole_trace"]["mfma_util_pct"], 1), "attn_bwd_dkdv_pct": pick("attn_bwd_dkdv"),
@@ -246,14 +246,14 @@ def main():
             avg_s = tot / cnt / 1e3
             traffic = None
             try:   # HBM bytes per call from the committed rocprofv3 PMC passes (FETCH_SIZE x2 corrected + WRITE_SIZE)
-                pm = json.load(open(ROOT / "profiles" / "r01_pmc_traffic.json"))
+                pm = json.load(open(ROOT / "profiles" / "r02_pmc_traffic.json"))
                 traffic = pm["fk_attn_bwd_bytes_per_call"] if bwd else None
             except Exception:
                 pass
             roof = {"kernel": "fk_attn_bwd (attn_bwd_dq [+ delta] and attn_bwd_dkdv launches of one call)" if bwd else "fk_attn_fwd",
                     "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(fl / avg_s / MFMA_PEAK_BF16, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r01_pmc_traffic.json); algorithmic bytes 1.21e9 with every tensor counted once; the two deterministic kernels (dQ, dK/dV) each have to read Q, K, V, dO, so their compulsory traffic is 1.82e9",
+                    "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r02_pmc_traffic.json); algorithmic bytes 1.21e9 with every tensor counted once; the two deterministic kernels (dQ, dK/dV) each have to read Q, K, V, dO, so their compulsory traffic is 1.82e9",
                     "flops_per_launch": fl, "avg_launch_ms": round(avg_s * 1e3, 3)}
         out = {
             "metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "value": round(value, 1), "unit": "frames/s",

@@ -719,8 +719,9 @@ def test_sample_topk_on_device(K):
     device-side step / position counters advance once per launch whatever the number of rows."""
     B, V, k, T = 3, 1000, 40, 0.8
     g = torch.Generator().manual_seed(3)
-    logits = torch.randn(B, 1024, generator=g)[:, :V] * 2.0            # row stride 1024 > V
-    lg = logits.cuda()
+    wide = torch.randn(B, 1024, generator=g) * 2.0
+    logits = wide[:, :V].contiguous()
+    lg = wide.cuda()[:, :V]                                             # row stride 1024 > V
     assert lg.stride(0) == 1024
     ref = logits / T
     kth = ref.topk(k, dim=-1).values[:, -1:]
