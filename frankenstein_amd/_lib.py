@@ -73,6 +73,9 @@ SIGNATURES = {
     "fk_ce_workspace_bytes": (_sz, [_i64]),
     "fk_ce_loss_fwd": (_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p, _sz, _p]),
     "fk_ce_loss_bwd": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),
+    "fk_ce_chunk_fwd": (_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _int, _p]),
+    "fk_ce_chunk_finish": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "fk_ce_chunk_bwd": (_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_adamw_step": (_int, [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _f64, _f64, _int, _p]),
 }
 

@@ -126,6 +126,59 @@ __global__ void ce_bwd_kernel(const T* logits, int64_t ld, const int64_t* target
   }
 }
 
+
+// ---- cross entropy over the vocabulary in CHUNKS (the head GEMM runs chunk by chunk; [rows, V] is never materialised) ----------------
+// running (max, sum exp, target logit) per row, merged with one fp32 chunk [rows, cw] whose first column is vocabulary index col0
+__global__ void ce_chunk_fwd_kernel(const float* logits, int64_t ld, const int64_t* targets, int64_t col0, float* row_m, float* row_s,
+                                    float* row_t, int cw, int first) {
+  __shared__ float sh[4];
+  const int64_t row = blockIdx.x;
+  const float* lr = logits + row * ld;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < cw; c += blockDim.x) mx = fmaxf(mx, lr[c]);
+  mx = block_max(mx, sh);
+  float s = 0.0f;
+  for (int c = threadIdx.x; c < cw; c += blockDim.x) s += __expf(lr[c] - mx);
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    const float m0 = first ? -INFINITY : row_m[row], s0 = first ? 0.0f : row_s[row];
+    const float mn = fmaxf(m0, mx);
+    row_m[row] = mn;
+    row_s[row] = (m0 == -INFINITY ? 0.0f : s0 * __expf(m0 - mn)) + s * __expf(mx - mn);
+    const int64_t t = targets[row] - col0;
+    if (first) row_t[row] = 0.0f;
+    if (t >= 0 && t < cw) row_t[row] = lr[t];
+  }
+}
+__global__ void ce_chunk_rows_kernel(const float* row_m, const float* row_s, const float* row_t, const int64_t* targets, float* row_lse,
+                                     float* nll, float* valid, int64_t rows, int64_t V, int64_t ignore_index) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const float lse = row_m[r] + logf(row_s[r]);
+    row_lse[r] = lse;
+    const int64_t t = targets[r];
+    const bool ok = (t != ignore_index) && t >= 0 && t < V;
+    nll[r] = ok ? lse - row_t[r] : 0.0f;
+    valid[r] = ok ? 1.0f : 0.0f;
+  }
+}
+// dlogits chunk = (softmax - onehot) * grad_out / #valid for valid rows, 0 otherwise; written in the compute dtype
+template <typename T>
+__global__ void ce_chunk_bwd_kernel(const float* logits, int64_t ld, const int64_t* targets, int64_t col0, const float* row_lse,
+                                    const float* loss_cnt, const float* gout, T* dl, int64_t ldd, int64_t rows, int cw, int cw_valid,
+                                    int64_t V, int64_t ignore_index) {
+  const int64_t total = rows * cw;
+  const float g = gout[0] / loss_cnt[1];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cw;
+    const int c = (int)(i % cw);
+    const int64_t t = targets[r];
+    const bool ok = (t != ignore_index) && t >= 0 && t < V;
+    float d = 0.0f;
+    if (ok && c < cw_valid) d = (__expf(logits[r * ld + c] - row_lse[r]) - (col0 + c == t ? 1.0f : 0.0f)) * g;
+    dl[r * ldd + c] = from_f32<T>(d);       // padded columns (c >= cw_valid) are written as zeros: they are GEMM operands
+  }
+}
+
 // ---- AdamW --------------------------------------------------------------------------------------------
 __global__ void adamw_kernel(float* p, float* g, float* m, float* v, int64_t n, float lr, float omb1, float b2, float omb2,
                              float eps, float wd, float bc1, float sqrt_bc2, float clip, float gscale, int zero_grad) {
@@ -227,6 +280,40 @@ int fk_ce_loss_bwd(const void* logits, int64_t ld, const int64_t* targets, const
   if (dtype == FK_BF16) hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(grid_for(rows * V, 16384)), dim3(TPB), 0, s, (const bf16_t*)logits, ld, targets, row_lse, loss2, grad_out, (bf16_t*)dlogits, ldd, rows, (int)V, ignore_index);
   else hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(grid_for(rows * V, 16384)), dim3(TPB), 0, s, (const float*)logits, ld, targets, row_lse, loss2, grad_out, (float*)dlogits, ldd, rows, (int)V, ignore_index);
   FK_CHECK_LAUNCH("fk_ce_loss_bwd");
+  return FK_OK;
+}
+
+int fk_ce_chunk_fwd(const float* logits, int64_t ld, const int64_t* targets, int64_t col0, float* row_m, float* row_s, float* row_t,
+                    int64_t rows, int64_t cw, int first, void* stream) {
+  FK_CHECK_ARG(logits && targets && row_m && row_s && row_t && rows > 0 && rows < (1LL << 31) && cw > 0 && cw < (1LL << 31) && ld >= cw && col0 >= 0,
+               "fk_ce_chunk_fwd: bad arguments");
+  hipLaunchKernelGGL(ce_chunk_fwd_kernel, dim3((unsigned)rows), dim3(TPB), 0, (hipStream_t)stream, logits, ld, targets, col0, row_m, row_s, row_t, (int)cw, first);
+  FK_CHECK_LAUNCH("fk_ce_chunk_fwd");
+  return FK_OK;
+}
+int fk_ce_chunk_finish(const float* row_m, const float* row_s, const float* row_t, const int64_t* targets, float* row_lse, float* loss2,
+                       int64_t rows, int64_t V, int64_t ignore_index, void* workspace, size_t workspace_bytes, void* stream) {
+  FK_CHECK_ARG(row_m && row_s && row_t && targets && row_lse && loss2 && rows > 0 && rows < (1LL << 31) && V > 0, "fk_ce_chunk_finish: bad arguments");
+  FK_CHECK_ARG(workspace && workspace_bytes >= (size_t)rows * 2 * sizeof(float), "fk_ce_chunk_finish: workspace too small");
+  float* nll = (float*)workspace;
+  float* valid = nll + rows;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_chunk_rows_kernel, dim3(grid_for(rows, 1024)), dim3(TPB), 0, s, row_m, row_s, row_t, targets, row_lse, nll, valid, rows, V, ignore_index);
+  FK_CHECK_LAUNCH("fk_ce_chunk_finish(rows)");
+  hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(TPB), 0, s, (const float*)nll, (const float*)valid, loss2, (int)rows);
+  FK_CHECK_LAUNCH("fk_ce_chunk_finish(final)");
+  return FK_OK;
+}
+int fk_ce_chunk_bwd(const float* logits, int64_t ld, const int64_t* targets, int64_t col0, const float* row_lse, const float* loss2,
+                    const float* grad_out, void* dlogits, int64_t ldd, int64_t rows, int64_t cw, int64_t cw_valid, int64_t V,
+                    int64_t ignore_index, int dtype, void* stream) {
+  FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, "fk_ce_chunk_bwd: bad dtype %d", dtype);
+  FK_CHECK_ARG(logits && targets && row_lse && loss2 && grad_out && dlogits && rows > 0 && cw > 0 && cw_valid >= 0 && cw_valid <= cw && ld >= cw_valid && ldd >= cw,
+               "fk_ce_chunk_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(ce_chunk_bwd_kernel<bf16_t>, dim3(grid_for(rows * cw, 16384)), dim3(TPB), 0, s, logits, ld, targets, col0, row_lse, loss2, grad_out, (bf16_t*)dlogits, ldd, rows, (int)cw, (int)cw_valid, V, ignore_index);
+  else hipLaunchKernelGGL(ce_chunk_bwd_kernel<float>, dim3(grid_for(rows * cw, 16384)), dim3(TPB), 0, s, logits, ld, targets, col0, row_lse, loss2, grad_out, (float*)dlogits, ldd, rows, (int)cw, (int)cw_valid, V, ignore_index);
+  FK_CHECK_LAUNCH("fk_ce_chunk_bwd");
   return FK_OK;
 }
 

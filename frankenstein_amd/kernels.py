@@ -581,6 +581,43 @@ def ce_loss_bwd(logits: Tensor, targets: Tensor, lse: Tensor, loss2: Tensor, gou
     return dlogits
 
 
+class CeChunkState:
+    """per-row running statistics of the chunked cross entropy (fk_ce_chunk_*)"""
+
+    def __init__(self, rows: int, device):
+        self.m = torch.empty(rows, dtype=torch.float32, device=device)
+        self.s = torch.empty(rows, dtype=torch.float32, device=device)
+        self.t = torch.empty(rows, dtype=torch.float32, device=device)
+        self.first = True
+
+
+def ce_chunk_fwd(logits: Tensor, targets: Tensor, col0: int, st: CeChunkState) -> None:
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1 and targets.dtype == torch.int64 and targets.is_contiguous()
+    rows, cw = logits.shape
+    call("fk_ce_chunk_fwd", logits.data_ptr(), logits.stride(0), targets.data_ptr(), col0, st.m.data_ptr(), st.s.data_ptr(), st.t.data_ptr(),
+         rows, cw, int(st.first), _stream())
+    st.first = False
+
+
+def ce_chunk_finish(st: CeChunkState, targets: Tensor, V: int, ignore_index: int = -100):
+    rows = targets.numel()
+    loss2 = torch.empty(2, dtype=torch.float32, device=targets.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=targets.device)
+    ws, nb = _ws(lib().fk_ce_workspace_bytes(rows), targets.device)
+    call("fk_ce_chunk_finish", st.m.data_ptr(), st.s.data_ptr(), st.t.data_ptr(), targets.data_ptr(), lse.data_ptr(), loss2.data_ptr(),
+         rows, V, ignore_index, _ptr(ws), nb, _stream())
+    return loss2, lse
+
+
+def ce_chunk_bwd(logits: Tensor, targets: Tensor, col0: int, cw_valid: int, lse: Tensor, loss2: Tensor, gout: Tensor, dl: Tensor, V: int,
+                 ignore_index: int = -100) -> Tensor:
+    rows, cw = dl.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and dl.stride(1) == 1 and logits.shape[0] == rows
+    call("fk_ce_chunk_bwd", logits.data_ptr(), logits.stride(0), targets.data_ptr(), col0, lse.data_ptr(), loss2.data_ptr(), gout.data_ptr(),
+         dl.data_ptr(), dl.stride(0), rows, cw, cw_valid, V, ignore_index, fk_dtype(dl), _stream())
+    return dl
+
+
 # ------------------------------------------------------------------------------------------- GPT embedding
 def gpt_embed_fwd(idx: Tensor, prefix: Optional[Tensor], wte: Tensor, wpe: Tensor, dtype: torch.dtype) -> Tensor:
     B, t_words = idx.shape

@@ -503,13 +503,18 @@ class BrainFormer(nn.Module):
             self.precompute_rope_cash = self.precompute_rope_cash.to(device=self.device)
         return self.precompute_rope_cash
 
-    def features(self, x):
-        """encoder -> learnable queries -> perceiver CrossBlocks -> ln_f -> head."""
+    def queries_out(self, x):
+        """encoder -> learnable queries -> perceiver CrossBlocks (before ln_f and the head)."""
         b = x.shape[0]
         ctx = self.encoder(x)
         q = E.ExpandQueries.apply(self.learnable_queries, b)
         for cross_block in self.perceiver.h:
             q = cross_block(q, ctx, self.self_attn_mask, self.cross_attn_mask, sa_rope=self.rope_cache)
+        return q
+
+    def features(self, x):
+        """encoder -> learnable queries -> perceiver CrossBlocks -> ln_f -> head."""
+        q = self.queries_out(x)
         head = self.perceiver[self.head_name]
         ln = self.perceiver.ln_f
         return E.NormLinear.apply(q, ln.weight, ln.bias, head.weight, head.bias, ln.eps, False)

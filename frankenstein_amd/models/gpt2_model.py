@@ -229,11 +229,15 @@ class GPT(nn.Module):
         x = _prep(x[:, -t_words:])            # keep only the text positions (strided-copy kernel)
         ln = self.transformer.ln_f
         if targets is not None:
-            logits = E.NormLinear.apply(x, ln.weight, ln.bias, self.lm_head.weight, None, ln.eps, False)
             # CE(logits[:, :-1], targets[:, 1:], ignore_index=-100) == CE over all rows with the targets shifted
             # left and the last position ignored (ignored rows contribute nothing to the mean)
             shifted = torch.full_like(targets, -100)
             shifted[:, :-1] = targets[:, 1:]
+            if getattr(self, "fuse_head_loss", False):
+                # the caller only wants the loss (train_utils.enable_fused_head_loss): the [B, t, 50257] logits are never materialised
+                loss = E.head_cross_entropy(x, ln.weight, ln.bias, self.lm_head.weight, None, shifted, ln.eps, -100, getattr(self, "head_chunk", 8192))
+                return loss, None
+            logits = E.NormLinear.apply(x, ln.weight, ln.bias, self.lm_head.weight, None, ln.eps, False)
             loss = E.cross_entropy(logits, shifted, -100)
         else:
             last = _prep(x[:, -1:, :])

@@ -32,6 +32,11 @@ class BrainFormerCE(_FileBrainFormer):
     head_name = 'to_words'
 
     def forward(self, x, targets=None, date_info=None):
+        if targets is not None and getattr(self, "fuse_head_loss", False):
+            # loss only (train_utils.enable_fused_head_loss): perceiver.ln_f -> to_words -> CE without the [B, tokens, V] logits
+            q = self.queries_out(x)
+            head, ln = self.perceiver[self.head_name], self.perceiver.ln_f
+            return E.head_cross_entropy(q, ln.weight, ln.bias, head.weight, head.bias, targets, ln.eps, -100, getattr(self, "head_chunk", 8192)), None
         logits = self.features(x)
         if targets is None:
             return None, logits

@@ -280,6 +280,18 @@ class FusedAdamW:
             g.update({k: v for k, v in src.items() if k != 'params'})
 
 
+def enable_fused_head_loss(model: torch.nn.Module, on: bool = True) -> int:
+    """Training loops that only use the loss (the reference's run_train_model discards the second output of model(...),
+    utils/train_utils.py:138-139) can let the vocabulary heads skip the [rows, 50257] logits: sets `fuse_head_loss` on every sub-module
+    that implements it (GPT, the notebook CE BrainFormer); their forward then returns (loss, None).  Returns how many were switched."""
+    n = 0
+    for m in model.modules():
+        if type(m).__name__ in ("GPT", "BrainFormerCE"):
+            m.fuse_head_loss = on
+            n += 1
+    return n
+
+
 # ------------------------------------------------------------------------------------------------ the step
 def train_step(model, batch, optimizer: FusedAdamW, step: int, cfg: TrainConfig, scheduler=None,
                micro_step: int = 0):

@@ -235,6 +235,20 @@ int fk_ce_loss_fwd(const void* logits, int64_t ld, const int64_t* targets, float
 int fk_ce_loss_bwd(const void* logits, int64_t ld, const int64_t* targets, const float* row_lse, const float* loss2,
                    const float* grad_out, void* dlogits, int64_t ldd, int64_t rows, int64_t V, int64_t ignore_index,
                    int dtype, void* stream);
+/* The same loss with the vocabulary processed in CHUNKS, for a head whose [rows, V] logits are never materialised (lm_head + CE of
+ * models/gpt2_model.py:205-210 at V = 50257): the caller runs the head GEMM chunk by chunk (fp32 output) and folds every chunk into
+ * per-row running statistics; the backward recomputes each chunk and gets its d-logits in the compute dtype (GEMM operand).
+ *   fk_ce_chunk_fwd   : merge chunk [rows, cw] (first vocabulary index col0) into row_m / row_s (running max / sum exp) and pick the
+ *                       target logit into row_t when the target falls into the chunk; first != 0 initialises the statistics.
+ *   fk_ce_chunk_finish: row_lse = row_m + log(row_s); loss2 = {mean nll over valid rows, #valid}  (workspace: fk_ce_workspace_bytes(rows)).
+ *   fk_ce_chunk_bwd   : dlogits[rows, cw] = (exp(logit - lse) - onehot) * grad_out / #valid on valid rows and columns < cw_valid, else 0. */
+int fk_ce_chunk_fwd(const float* logits, int64_t ld, const int64_t* targets, int64_t col0, float* row_m, float* row_s, float* row_t,
+                    int64_t rows, int64_t cw, int first, void* stream);
+int fk_ce_chunk_finish(const float* row_m, const float* row_s, const float* row_t, const int64_t* targets, float* row_lse, float* loss2,
+                       int64_t rows, int64_t V, int64_t ignore_index, void* workspace, size_t workspace_bytes, void* stream);
+int fk_ce_chunk_bwd(const float* logits, int64_t ld, const int64_t* targets, int64_t col0, const float* row_lse, const float* loss2,
+                    const float* grad_out, void* dlogits, int64_t ldd, int64_t rows, int64_t cw, int64_t cw_valid, int64_t V,
+                    int64_t ignore_index, int dtype, void* stream);
 
 /* ---- optimizer: torch.optim.AdamW step fused with clip_grad_value_ (utils/train_utils.py:117-119,142-143) over a
  *      flat fp32 arena: g' = clamp(g * grad_scale, -clip, clip) (clip <= 0: no clamp); p *= 1 - lr*wd;

@@ -344,6 +344,54 @@ def test_cfg2_b1_ce_head(golden, mode):
         fa.set_compute_dtype("fp32")
 
 
+@pytest.mark.parametrize("bias", [True, False])
+def test_fused_head_loss_gpt_matches_reference(golden, bias):
+    """lm_head + cross entropy with the vocabulary processed in chunks (no [rows, V] logits; train_utils.enable_fused_head_loss): the
+    reference's loss and EVERY gradient, V = 211 in chunks of 64 (ragged last chunk, V not a multiple of the vector width)."""
+    from frankenstein_amd.utils import train_utils as tu
+    z = golden(f"gpt_small_bias{int(bias)}")
+    cfgo, prefix, tk, idx = C.gpt_small(bias)
+    g = load_synth(mk_gpt(cfgo))
+    assert tu.enable_fused_head_loss(g) == 1
+    g.head_chunk = 64
+    pf = prefix.cuda().requires_grad_(True)
+    loss, logits = g(idx.cuda(), prefix=pf, targets=tk.cuda())
+    assert logits is None and abs(float(loss) - float(z["loss"])) < 1e-5
+    loss.backward()
+    np.testing.assert_allclose(pf.grad.cpu().numpy(), z["prefix_grad"], rtol=1e-3, atol=1e-6)
+    check_full_grads(g, z)
+    g.fuse_head_loss = False                        # and the plain path still returns the logits
+    _, lg = g(idx.cuda(), prefix=pf.detach(), targets=tk.cuda())
+    np.testing.assert_allclose(lg.float().cpu().detach().numpy(), z["logits"], atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_fused_head_loss_cfg2_ce(golden, mode):
+    """cfg2's CE head (V = 50257, 25 tokens) through the chunked head + loss: fp32 mode pins loss and gradient rows to the reference,
+    bf16 mode stays within the bounds of the unfused bf16 test; the bias of `to_words` takes part."""
+    from frankenstein_amd.models.notebook_models import BrainFormerCE
+    from frankenstein_amd.utils import train_utils as tu
+    z = golden("cfg2_b1_ce")
+    fa.set_compute_dtype(mode)
+    try:
+        cfgo, x, tok = C.cfg2_ce(1)
+        m = mk_bf(cfgo, BrainFormerCE)
+        assert tu.enable_fused_head_loss(m) == 1
+        loss, logits = m(x.cuda(), tok.cuda())
+        assert logits is None
+        loss.backward()
+        cos = _cosines(m, z)
+        if mode == "fp32":
+            assert abs(float(loss) - float(z["loss"])) < 1e-4
+            check_grad_rows(m, z, rtol=5e-3, atol=5e-4)
+            assert min(cos.values()) > 0.9999
+        else:
+            assert abs(float(loss) - float(z["loss"])) / float(z["loss"]) < 1e-2
+            assert min(cos.values()) >= 0.99, min(cos.items(), key=lambda kv: kv[1])
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
 def test_bf16_drift_small():
     """bf16 throughput mode vs the fp32 CPU oracle on the small model: bounded drift, same loss to ~1e-2."""
     from frankenstein_amd.models import brainformer as bf
