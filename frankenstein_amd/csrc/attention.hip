@@ -1147,7 +1147,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) 
       }
     }
     dl = part + __shfl_xor(part, 32, 64);
-    if (q_ok && lh == 0) p.delta[stat] = dl;
+    // published for the dK/dV kernel in the form it consumes, as two rows of length Nq rounded up to its 64-row tile:
+    //   ws[0][b, h, q] = -LSE * log2(e)   (-inf for rows past Nq and fully masked rows: P = 0),   ws[1][b, h, q] = -delta  (0 past Nq)
+    const int nqp = (p.Nq + 63) / 64 * 64;
+    if (lh == 0 && qrow < nqp) {
+      const int64_t pst = ((int64_t)b * p.H + hd) * nqp + qrow;
+      p.delta[pst] = -lse2;
+      p.delta[(int64_t)p.B * p.H * nqp + pst] = q_ok ? -dl : 0.0f;
+    }
   }
   f32x16 cl, cd;       // the row constants as initial accumulators: S' = Q'K^T - lse2, dP' = dO V^T - delta
 #pragma unroll
@@ -1286,44 +1293,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
   const int qs = keypad ? 0 : (q_first(p, b, k0) / TQ) * TQ;
   const int ntiles = qs < p.Nq ? (p.Nq - qs + TQ - 1) / TQ : 0;
   const int full_vis_q = q_first(p, b, min(k0 + wave * 32 + 31, p.Nk - 1));
-  const int64_t stat0 = ((int64_t)b * p.H + hd) * p.Nq;
-
-  // Row statistics travel one step behind their tile's DMA: loaded (wave 0, raw loads only: arithmetic on the value would force an
-  // early vmcnt wait) when the tile is requested, two tiles ahead, and written to LDS one step later, when only the NEXT request is
-  // younger in the vmcnt queue: the compiler's wait for these two registers then leaves that request in flight.
-  float st_l = 0.0f, st_d = 0.0f, nx_l = 0.0f, nx_d = 0.0f;
-  bool st_ok = false, nx_ok = false;
-  auto load_stats = [&](int qb) {
-    st_l = nx_l; st_d = nx_d; st_ok = nx_ok;
-    if (tid < TQ) {
-      const int q = qb + tid;
-      nx_ok = q < p.Nq;
-      if (nx_ok) {
-        nx_l = p.LSE[stat0 + q];
-        nx_d = p.delta[stat0 + q];
-      }
+  // Row statistics: the dQ kernel has left -LSE*log2(e) and -delta in the workspace exactly as the accumulators want them (rows padded to
+  // the tile, -inf / 0 past Nq), so a tile's 64 + 64 floats travel by LDS-DMA like the tile itself: one 256-byte piece each, issued by
+  // waves 0 and 1 (no statistics registers, no arithmetic, no LDS stores in this kernel any more).
+  const int nqp = (p.Nq + 63) / 64 * 64;
+  const float* nl_g = p.delta + ((int64_t)b * p.H + hd) * nqp;
+  const float* nd_g = nl_g + (int64_t)p.B * p.H * nqp;
+  auto request_stats = [&](int qb, int slot) __attribute__((always_inline)) {
+    if (wave < 2) {
+      const float* src = (wave == 0 ? nl_g : nd_g) + qb + lane;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(stats + slot * 2 * TQ + wave * TQ), 4, 0, 0);
     }
   };
-  auto store_stats = [&](int buf) {      // the OLDER set (st_*)
-    if (tid < TQ) {
-      stats[buf * 2 * TQ + tid] = st_ok ? -(st_l * LOG2E) : -INFINITY;
-      stats[buf * 2 * TQ + TQ + tid] = st_ok ? -st_d : 0.0f;
-    }
+  DmaCursor<TQ, NW> qcur, gcur;
+  auto request_tile = [&](int qb, int slot) __attribute__((always_inline)) {
+    qcur.next(Qp, p.q_rs, qb, p.Nq, qimg(slot), wave, lane);
+    gcur.next(Gp, p.o_rs, qb, p.Nq, gimg(slot), wave, lane);
+    request_stats(qb, slot);
   };
   if (ntiles > 0) {
-    dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qs, p.Nq, qimg(0), wave, lane);
-    dma_tile_bf16_d64<TQ, NW>(Gp, p.o_rs, qs, p.Nq, gimg(0), wave, lane);
-    load_stats(qs);
-    if (ntiles > 1) {
-      dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qs + TQ, p.Nq, qimg(1), wave, lane);
-      dma_tile_bf16_d64<TQ, NW>(Gp, p.o_rs, qs + TQ, p.Nq, gimg(1), wave, lane);
-    }
-    load_stats(qs + TQ);                 // (rows past Nq load nothing)  st_* = tile 0, nx_* = tile 1
-    store_stats(0);
+    qcur.init(Qp, p.q_rs, qs, wave, lane);
+    gcur.init(Gp, p.o_rs, qs, wave, lane);
+    request_tile(qs, 0);
+    if (ntiles > 1) request_tile(qs + TQ, 1);
   }
-  // tile 0 and its statistics have landed; tile 1 (pieces + wave 0's two statistics loads) may stay in flight
-  auto wait_next = [&]() {
-    if (wave == 0) { if constexpr (PCS == 4) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  // tile t+1 has landed (all but this step's own pieces: PCS, plus the statistics piece of waves 0 and 1), tile t+2 stays in flight
+  auto wait_next = [&]() __attribute__((always_inline)) {
+    static_assert(PCS == 4 || PCS == 2, "vmcnt immediates");
+    if (wave < 2) { if constexpr (PCS == 4) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
     else { if constexpr (PCS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
   };
   if (ntiles > 1) wait_next(); else dma_wait_barrier();
@@ -1337,14 +1334,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
     const int qb = qs + t * TQ;
     // request tile t+2: slot (SLOT + 2) % 3 held tile t-1, which every wave left at the barrier that ended the previous step (an LDS-DMA
     // piece costs the issuing wave ~190 cycles, measured with -DFK_STAMP, wherever in the step it is issued)
-    auto request = [&]() {
-      if (t + 2 < ntiles) {
-        dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qb + 2 * TQ, p.Nq, qimg((SLOT + 2) % NS), wave, lane);
-        dma_tile_bf16_d64<TQ, NW>(Gp, p.o_rs, qb + 2 * TQ, p.Nq, gimg((SLOT + 2) % NS), wave, lane);
-      }
-      if (t + 1 < ntiles) load_stats(qb + 2 * TQ);      // st_* <- tile t+1 (requested one step ago), nx_* <- tile t+2 (nothing past Nq)
-    };
-    request();
+    if (t + 2 < ntiles) request_tile(qb + 2 * TQ, (SLOT + 2) % NS);
     FK_ST(0)
     const char* qt = qimg(SLOT);
     const char* gt = gimg(SLOT);
@@ -1410,7 +1400,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
       }
       FK_ST(3)
     }
-    if (t + 1 < ntiles) store_stats((SLOT + 1) % NS);
     FK_ST(4)
     // tile t+1 (and wave 0's statistics of it) has landed, the request for tile t+2 stays in flight across the barrier
     if (t + 2 < ntiles) wait_next(); else dma_wait_barrier();

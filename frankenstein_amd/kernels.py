@@ -243,7 +243,7 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     (qb, qr), (kb, kr), (vb, vr), (ob, orr) = _bnhd(q), _bnhd(k), _bnhd(v), _bnhd(o)
     assert _bnhd(dq) == (qb, qr) and _bnhd(dk) == (kb, kr) and _bnhd(dv) == (vb, vr) and _bnhd(do) == (ob, orr)
     assert do.dtype == q.dtype and dq.dtype == q.dtype
-    delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    delta = torch.empty(2 * B * H * ((Nq + 63) // 64 * 64), dtype=torch.float32, device=q.device)     # scratch: row statistics for dK/dV
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
     with _timed(f"attn_bwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
       call("fk_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),

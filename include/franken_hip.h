@@ -87,7 +87,7 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
  * visible(q,k) = k < limits[b,q] <=> q >= qfirst[b,k], int32 tables from fk_prefix_mask.
  * KEYPAD (padding mask of models/simple_mae:228-236,349-352): visible(q,k) = limits[b,q] != 0 && qfirst[b,k] != 0, i.e. the two
  * int32 tables are the query / key validity flags.  Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
- * Q/K/V's strides; delta_ws is [B,H,Nq] fp32 scratch.  rope_table != NULL (self-attention only) additionally applies the
+ * Q/K/V's strides; delta_ws is fp32 scratch of 2 * B * H * roundup(Nq, 64) floats (the row statistics the dQ kernel hands to the dK/dV kernel).  rope_table != NULL (self-attention only) additionally applies the
  * inverse RoPE (rotation by -angle at position rope_off + index) to dQ and dK as they are stored = apply_rope's backward.                                                        */
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
                 int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
