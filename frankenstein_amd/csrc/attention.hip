@@ -1253,6 +1253,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) 
     store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
 }
 
+#ifdef FK_DKDV_ASM
+#include "attn_dkdv_asm.inc"      // generated by tools/gen/gen_dkdv_asm.py: hand-placed instruction stream of one fully visible tile step
+#endif
 // ------------------------------------------------------------------------------------------------- dK, dV (pre-scaled Q)
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p) {
@@ -1423,6 +1426,99 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
   FK_ST_FLUSH(0)
 }
 
+#ifdef FK_DKDV_ASM
+// ------------------------------------------------------------------------------------------------- dK, dV: hand-placed stream
+// The fully visible, fully aligned case (every tile of every workgroup visible to all its keys: no mask or a block-causal mask whose
+// block is a multiple of 128 keys and of the 64-query tile, no offsets, Nk % 128 == 0, Nq % 64 == 0 — the benchmark's shape) runs the
+// generated instruction stream of attn_dkdv_asm.inc; everything else stays on attn_bwd_dkdv_ps_kernel.  The kernel around the stream
+// is kept small on purpose: the stream owns v100-v243, the compiler the remaining 112 registers (dK/dV accumulators 64, K/V fragments 32,
+// seven LDS addresses).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_asm_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64, TQ = 64, BK = 128, NW = 4, IMG = TQ * 128, NS = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto qimg = [&](int i) -> char* { return smem + i * IMG; };
+  auto gimg = [&](int i) -> char* { return smem + (NS + i) * IMG; };
+  float* stats = reinterpret_cast<float*>(smem + 2 * NS * IMG);
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkb = p.Nk / BK;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nkb), b = bh / p.H, hd = bh % p.H, k0 = (int)(L % nkb) * BK;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const int krow = k0 + wave * 32 + li;
+  bf16x8 kfv[4], vfv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kfv[s] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)krow * p.k_rs + 16 * s + 8 * lh);
+    vfv[s] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)krow * p.v_rs + 16 * s + 8 * lh);
+  }
+  const int qs = q_first(p, b, k0);                      // a multiple of the mask block, hence of TQ
+  const int ntiles = (p.Nq - qs) / TQ;
+  const int nqp = p.Nq;
+  const float* nl_g = p.delta + ((int64_t)b * p.H + hd) * nqp;
+  const float* nd_g = nl_g + (int64_t)p.B * p.H * nqp;
+  auto request_tile = [&](int qb, int slot) __attribute__((always_inline)) {
+    dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qb, p.Nq, qimg(slot), wave, lane);
+    dma_tile_bf16_d64<TQ, NW>(Gp, p.o_rs, qb, p.Nq, gimg(slot), wave, lane);
+    if (wave < 2) {
+      const float* src = (wave == 0 ? nl_g : nd_g) + qb + lane;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(stats + slot * 2 * TQ + wave * TQ), 4, 0, 0);
+    }
+  };
+  if (ntiles > 0) {
+    request_tile(qs, 0);
+    if (ntiles > 1) request_tile(qs + TQ, 1);
+  }
+  auto wait_next = [&]() __attribute__((always_inline)) {
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  if (ntiles > 1) wait_next(); else dma_wait_barrier();
+  f32x16 dk[2], dv[2];
+  zero_acc(dk);
+  zero_acc(dv);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  unsigned aq[4], va0, va1;
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) aq[s_] = lds0 + (unsigned)Img<T, D>::off(li, (16 * s_ + 8 * lh) * 2);
+  {
+    const int g4 = lane >> 4, i16 = lane & 15, hh = g4 >> 1;
+    const int rpart = (4 * hh + (i16 >> 2)) * 128 + (i16 & 1) * 8;
+    const int c0 = 2 * (g4 & 1) + ((i16 & 3) >> 1), gg0 = 2 * hh + (i16 >> 3), f0 = gg0 ^ ((gg0 & 1) << 2);
+    va0 = lds0 + (unsigned)(rpart + ((c0 ^ f0) << 4));
+    va1 = lds0 + (unsigned)(rpart + (((c0 ^ f0) ^ 4) << 4));
+  }
+  const unsigned ast = lds0 + (unsigned)(2 * NS * IMG) + (unsigned)lh * 16u;
+  for (int t = 0; t < ntiles; t += 3) {
+    if (t + 2 < ntiles) request_tile(qs + (t + 2) * TQ, 2);
+    dkdv_tile_asm_slot0(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast);
+    if (t + 2 < ntiles) wait_next(); else dma_wait_barrier();
+    if (t + 1 < ntiles) {
+      if (t + 3 < ntiles) request_tile(qs + (t + 3) * TQ, 0);
+      dkdv_tile_asm_slot1(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast);
+      if (t + 3 < ntiles) wait_next(); else dma_wait_barrier();
+    }
+    if (t + 2 < ntiles) {
+      if (t + 4 < ntiles) request_tile(qs + (t + 4) * TQ, 1);
+      dkdv_tile_asm_slot2(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast);
+      if (t + 4 < ntiles) wait_next(); else dma_wait_barrier();
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the stream's last MFMAs have retired before the compiler reads the accumulators
+  T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
+  T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
+  if (p.rope_table)
+    store_rows_T_rope<T, D>(dKp, p.k_rs, krow, true, dk, LN2, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + krow) * D);
+  else
+    store_rows_T<T, D>(dKp, p.k_rs, krow, true, dk, LN2, lh);
+  store_rows_T<T, D>(dVp, p.v_rs, krow, true, dv, 1.0f, lh);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------- host
 template <typename T, int D> size_t fwd_lds() {
   return Img<T, D>::SWZ ? (size_t)3 * 2 * BKV * 128 : (size_t)2 * BKV * (AT<T, D>::RSTRIDE + AT<T, D>::VSTRIDE);
@@ -1473,9 +1569,19 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
     if (a.flags & FK_ATTN_Q_PRESCALED) {
       constexpr int NWQ = FK_DQ_NW, NWK = FK_DKDV_NW;
       dim3 gq2((unsigned)(((a.Nq + NWQ * 32 - 1) / (NWQ * 32)) * a.H * a.B)), gk2((unsigned)(((a.Nk + NWK * 32 - 1) / (NWK * 32)) * a.H * a.B));
-      allow_lds(attn_bwd_dkdv_ps_kernel<NWK>, DKDV_PS_LDS);
       allow_lds(attn_bwd_dq_ps_kernel<NWQ>, DQ_PS_LDS);
       hipLaunchKernelGGL(attn_bwd_dq_ps_kernel<NWQ>, gq2, dim3(NWQ * 64), DQ_PS_LDS, s, a);
+#ifdef FK_DKDV_ASM
+      // every tile of every workgroup fully visible and aligned -> the generated instruction stream
+      const bool aligned = a.Nk % 128 == 0 && a.Nq % 64 == 0 && a.q_off == 0 && a.k_off == 0 &&
+                           (a.mask_kind == FK_MASK_NONE || (a.mask_kind == FK_MASK_BLOCK_CAUSAL && a.mask_c % 128 == 0));
+      if (aligned) {
+        allow_lds(attn_bwd_dkdv_asm_kernel, DKDV_PS_LDS);
+        hipLaunchKernelGGL(attn_bwd_dkdv_asm_kernel, gk2, dim3(256), DKDV_PS_LDS, s, a);
+        return 0;
+      }
+#endif
+      allow_lds(attn_bwd_dkdv_ps_kernel<NWK>, DKDV_PS_LDS);
       hipLaunchKernelGGL(attn_bwd_dkdv_ps_kernel<NWK>, gk2, dim3(NWK * 64), DKDV_PS_LDS, s, a);
       return 0;
     }

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Generates frankenstein_amd/csrc/attn_dkdv_asm.inc: the hand-placed instruction stream of one fully visible tile step of the dK/dV
+attention-backward kernel (bf16, D = 64, 32 keys per wave, 64-query tile = two 32-row halves u = 0, 1) as ONE inline-asm block per ring slot.
+
+Why generated: hipcc schedules this loop as matrix phase -> VALU phase -> matrix phase (or, given one basic block, waits on every LDS read in
+front of its MFMA); on a SIMD the phases of the co-resident waves then ADD.  Here the 32 MFMAs of a tile step are a fixed
+sequence and every gap behind an MFMA gets its share of the LDS reads and of the VALU work explicitly (earliest-deadline-first over release
+/ deadline windows derived from the data flow and the register reuse):
+
+  MFMA  1.. 8   S'/dP' of half 0        | gaps: transposed reads of half 0, row reads of half 1, statistics of half 1
+  MFMA  9..16   S'/dP' of half 1        | gaps: exp2 / dS / bf16 packing of half 0
+  MFMA 17..24   dV/dK of half 0         | gaps: exp2 / dS / packing of half 1, transposed reads of half 1 (slot by slot as they free up)
+  MFMA 25..32   dV/dK of half 1         | gaps: the rest of the packing of half 1
+
+Register map (hard-coded temporaries, listed as clobbers so hipcc keeps its own values out of them):
+  SC0 v[100:115]  DP0 v[116:131]  SC1 v[132:147]  DP1 v[148:163]     scores / dP of the two halves (accumulators, then P / dS in place)
+  ROW v[164:195]  four k-steps x (Q fragment 4, dO fragment 4); the first 16 are reused for the packed P / dS of half 1
+  TR  v[196:227]  eight transposed fragments x 4 (dO^T, Q^T for (s, dt))
+  PK  v[228:243]  packed P (s = 0, 1) and dS (s = 0, 1) of half 0
+Operands: dk0 dk1 dv0 dv1 (f32x16, read-write), kf0..3 vf0..3 (bf16x8), aq0..3 (row-read byte addresses in the Q image of slot 0),
+va0 va1 (transposed-read byte addresses), ast (statistics byte address, slot 0).
+LDS reads return in order, so every wait is a counted s_waitcnt lgkmcnt(n) computed by the model below.
+Hazards kept by construction: a VALU result is consumed (by VALU or as an MFMA operand) at least 2 instructions later; an MFMA result is
+read by VALU only after two further MFMAs; an LDS read overwrites a fragment register only after the MFMA that read it AND one more MFMA
+have been issued.
+"""
+import os
+import sys
+
+IMG, NS = 64 * 128, 3
+SC = [100, 132]
+DP = [116, 148]
+ROW, TR, PK = 164, 196, 228
+LDS_PER_GAP = int(os.environ.get("FK_GEN_LDS_PER_GAP", "2"))
+VALU_UNITS = int(os.environ.get("FK_GEN_VALU_UNITS", "7"))       # issue budget of a gap in 4-cycle units (exp2 = 2)
+
+
+def vr(a, n=1):
+    return f"v{a}" if n == 1 else f"v[{a}:{a + n - 1}]"
+
+
+class Model:
+    def __init__(self):
+        self.out, self.reads, self.done = [], [], set()
+
+    def emit(self, s):
+        self.out.append(s)
+
+    def lds(self, rid, text):
+        self.reads.append(rid)
+        self.out.append(text)
+
+    def need(self, rids):
+        rids = [r for r in rids if r not in self.done]
+        if not rids:
+            return
+        last = max(self.reads.index(r) for r in rids)
+        self.out.append(f"s_waitcnt lgkmcnt({min(len(self.reads) - 1 - last, 15)})")
+        self.done.update(self.reads[:last + 1])
+        self.reads = self.reads[last + 1:]
+
+
+def tr_reg(s, dt, w):
+    return TR + 4 * ((s * 2 + dt) * 2 + w)
+
+
+def gen(slot):
+    qoff, soff = slot * IMG, slot * 2 * 64 * 4
+    goff = qoff + NS * IMG
+    M = Model()
+
+    # ------------------------------------------------------------------ the 32 MFMAs: (text, LDS reads needed, VALU results needed)
+    mf = [None]
+    for u in range(2):
+        for s in range(4):
+            st_sc = [("st", u, 0, g) for g in range(4)] if s == 0 else []
+            st_dp = [("st", u, 1, g) for g in range(4)] if s == 0 else []
+            mf.append((f"v_mfma_f32_32x32x16_bf16 {vr(SC[u], 16)}, {vr(ROW + 8 * s, 4)}, %[kf{s}], {vr(SC[u], 16)}", [("rq", u, s)] + st_sc, []))
+            mf.append((f"v_mfma_f32_32x32x16_bf16 {vr(DP[u], 16)}, {vr(ROW + 8 * s + 4, 4)}, %[vf{s}], {vr(DP[u], 16)}", [("rg", u, s)] + st_dp, []))
+    for u in range(2):
+        pk = PK if u == 0 else ROW
+        for s in range(2):
+            for dt in range(2):
+                for w, acc in ((0, "dv"), (1, "dk")):
+                    b = pk + 4 * s + (0 if w == 0 else 8)
+                    vneed = [("cp" if w == 0 else "cd", u, 4 * s + j) for j in range(4)]
+                    mf.append((f"v_mfma_f32_32x32x16_bf16 %[{acc}{dt}], {vr(tr_reg(s, dt, w), 4)}, {vr(b, 4)}, %[{acc}{dt}]",
+                               [("tr", u, s, dt, w, t) for t in range(2)], vneed))
+    assert len(mf) == 33
+
+    # ------------------------------------------------------------------ LDS read tasks: id -> (text, release gap, deadline MFMA)
+    lds = {}
+    for u in range(2):
+        for g in range(4):
+            lds[("st", u, 0, g)] = (f"ds_read_b128 {vr(SC[u] + 4 * g, 4)}, %[ast] offset:{soff + (32 * u + 8 * g) * 4}", 0, 1 + 8 * u)
+            lds[("st", u, 1, g)] = (f"ds_read_b128 {vr(DP[u] + 4 * g, 4)}, %[ast] offset:{soff + 256 + (32 * u + 8 * g) * 4}", 0, 2 + 8 * u)
+        for s in range(4):
+            rel = 0 if u == 0 else 2 * s + 3                 # half 1 reuses the slot: its two MFMAs (2s+1, 2s+2) and one more are out
+            lds[("rq", u, s)] = (f"ds_read_b128 {vr(ROW + 8 * s, 4)}, %[aq{s}] offset:{qoff + 4096 * u}", rel, 8 * u + 2 * s + 1)
+            lds[("rg", u, s)] = (f"ds_read_b128 {vr(ROW + 8 * s + 4, 4)}, %[aq{s}] offset:{goff + 4096 * u}", rel, 8 * u + 2 * s + 2)
+        for s in range(2):
+            for dt in range(2):
+                for w in range(2):
+                    f = (s * 2 + dt) * 2 + w
+                    for t in range(2):
+                        base = goff if w == 0 else qoff
+                        rel = 0 if u == 0 else 17 + f + 1         # the slot's half-0 fragment is read by MFMA 17 + f
+                        lds[("tr", u, s, dt, w, t)] = (
+                            f"ds_read_b64_tr_b16 {vr(tr_reg(s, dt, w) + 2 * t, 2)}, %[va{dt ^ t}] offset:{base + 4096 * u + (16 * s + 8 * t) * 128}",
+                            rel, 17 + 8 * u + f)
+    # ------------------------------------------------------------------ VALU tasks: id -> (text, cost, release gap, deadline MFMA, producers)
+    va = {}
+    for u in range(2):
+        pk = PK if u == 0 else ROW
+        rel_e, rel_m = 9 + 8 * u, 10 + 8 * u                  # S' of half u is final with MFMA 7 + 8u, dP' with 8 + 8u: two MFMAs on
+        for r in range(16):
+            s, j = r // 8, (r % 8) // 2
+            dl_p, dl_d = 17 + 8 * u + 4 * s, 18 + 8 * u + 4 * s
+            va[("e", u, r)] = (f"v_exp_f32_e32 {vr(SC[u] + r)}, {vr(SC[u] + r)}", 2, rel_e, dl_p, [])
+            va[("m", u, r)] = (f"v_mul_f32_e32 {vr(DP[u] + r)}, {vr(DP[u] + r)}, {vr(SC[u] + r)}", 1, rel_m, dl_d, [("e", u, r)])
+        for sj in range(8):
+            s, j = divmod(sj, 4)
+            va[("cp", u, sj)] = (f"v_cvt_pk_bf16_f32 {vr(pk + 4 * s + j)}, {vr(SC[u] + 8 * s + 2 * j)}, {vr(SC[u] + 8 * s + 2 * j + 1)}", 1, rel_e,
+                                 17 + 8 * u + 4 * s, [("e", u, 8 * s + 2 * j), ("e", u, 8 * s + 2 * j + 1)])
+            va[("cd", u, sj)] = (f"v_cvt_pk_bf16_f32 {vr(pk + 8 + 4 * s + j)}, {vr(DP[u] + 8 * s + 2 * j)}, {vr(DP[u] + 8 * s + 2 * j + 1)}", 1, rel_m,
+                                 18 + 8 * u + 4 * s, [("m", u, 8 * s + 2 * j), ("m", u, 8 * s + 2 * j + 1)])
+    # the packed P / dS of half 1 overwrite row-fragment registers of k-steps 0 and 1, last read by MFMAs 11 / 12: free from gap 13 on (fine)
+
+    lds_todo = dict(lds)
+    va_todo = dict(va)
+    va_pos = {}
+
+    def issue_lds(gap, cap, only_due=None):
+        n = 0
+        while n < cap:
+            cands = [(v[2], k) for k, v in lds_todo.items() if v[1] <= gap and (only_due is None or v[2] <= only_due)]
+            if not cands:
+                break
+            _, k = min(cands)
+            M.lds(k, lds_todo.pop(k)[0])
+            n += 1
+
+    def issue_valu(gap, units):
+        while units > 0:
+            n = len(M.out)
+            cands = [(v[3], k) for k, v in va_todo.items()
+                     if v[2] <= gap and v[1] <= units and all(d in va_pos and n - va_pos[d] >= 2 for d in v[4])]
+            if not cands:
+                break
+            _, k = min(cands)
+            v = va_todo.pop(k)
+            va_pos[k] = len(M.out)
+            M.emit(v[0])
+            units -= v[1]
+
+    # gap 0: what the first two MFMAs need, nothing else (a long burst fills the LDS command queue and stalls the issue of everything behind it)
+    issue_lds(0, 99, only_due=1)
+    for g in range(1, 33):
+        text, lneed, vneed = mf[g]
+        # late producers: VALU results this MFMA consumes must exist (and be 2 instructions old); flush them if the gaps did not fit them
+        missing = [k for k in vneed if k in va_todo]
+        while missing:
+            before = len(va_todo)
+            issue_valu(99, 99)
+            missing = [k for k in vneed if k in va_todo]
+            if len(va_todo) == before:
+                M.emit("s_nop 0")
+        while any(len(M.out) - va_pos[k] < 2 for k in vneed):
+            M.emit("s_nop 0")
+        for k in lneed:
+            if k in lds_todo:                                   # not released / scheduled in time: issue now
+                M.lds(k, lds_todo.pop(k)[0])
+        M.need(lneed)
+        M.emit(text)
+        if g == 1:
+            issue_lds(1, 99, only_due=2)                        # the second MFMA's statistics and dO fragment
+        issue_lds(g, LDS_PER_GAP)
+        issue_valu(g, VALU_UNITS)
+    assert not lds_todo and not va_todo and not M.reads, (lds_todo.keys(), va_todo.keys(), M.reads)
+    return M.out
+
+
+def main():
+    out = sys.argv[1]
+    clob = ", ".join(f'"v{r}"' for r in range(100, 244))
+    with open(out, "w") as f:
+        f.write("// GENERATED by tools/gen/gen_dkdv_asm.py - do not edit.  One fully visible dK/dV tile step per ring slot (see the generator's header).\n")
+        for slot in range(NS):
+            ins = gen(slot)
+            f.write(f"FK_DEV void dkdv_tile_asm_slot{slot}(f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4],\n"
+                    f"                                   const unsigned (&aq)[4], unsigned va0, unsigned va1, unsigned ast) {{\n")
+            f.write("  asm volatile(\n")
+            for i in ins:
+                f.write(f'      "{i}\\n\\t"\n')
+            f.write('      : [dk0] "+v"(dk0), [dk1] "+v"(dk1), [dv0] "+v"(dv0), [dv1] "+v"(dv1)\n')
+            f.write('      : [kf0] "v"(kf[0]), [kf1] "v"(kf[1]), [kf2] "v"(kf[2]), [kf3] "v"(kf[3]), [vf0] "v"(vf[0]), [vf1] "v"(vf[1]), [vf2] "v"(vf[2]), [vf3] "v"(vf[3]),\n')
+            f.write('        [aq0] "v"(aq[0]), [aq1] "v"(aq[1]), [aq2] "v"(aq[2]), [aq3] "v"(aq[3]), [va0] "v"(va0), [va1] "v"(va1), [ast] "v"(ast)\n')
+            f.write(f"      : {clob}, \"memory\");\n}}\n")
+        f.write(f"// instructions per tile step: {len(ins)}\n")
+    print(f"{out}: {len(ins)} instructions per tile step")
+
+
+if __name__ == "__main__":
+    main()
