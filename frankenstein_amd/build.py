@@ -26,7 +26,7 @@ def _stale(out: Path, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    hdrs = [CSRC / "fk_common.h", HERE.parent / "include" / "franken_hip.h"]
+    hdrs = [CSRC / "fk_common.h", HERE.parent / "include" / "franken_hip.h", *sorted(CSRC.glob("*.inc"))]   # *.inc: generated streams (tools/gen)
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     jobs = []

@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) 
     store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
 }
 
-#ifdef FK_DKDV_ASM
+#ifndef FK_NO_DKDV_ASM
 #include "attn_dkdv_asm.inc"      // generated by tools/gen/gen_dkdv_asm.py: hand-placed instruction stream of one fully visible tile step
 #endif
 // ------------------------------------------------------------------------------------------------- dK, dV (pre-scaled Q)
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
   FK_ST_FLUSH(0)
 }
 
-#ifdef FK_DKDV_ASM
+#ifndef FK_NO_DKDV_ASM
 // ------------------------------------------------------------------------------------------------- dK, dV: hand-placed stream
 // The fully visible, fully aligned case (every tile of every workgroup visible to all its keys: no mask or a block-causal mask whose
 // block is a multiple of 128 keys and of the 64-query tile, no offsets, Nk % 128 == 0, Nq % 64 == 0 — the benchmark's shape) runs the
@@ -1450,38 +1450,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_asm_kernel(AttnArgs p) {
   const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
   const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
   const int krow = k0 + wave * 32 + li;
+  const int qs = q_first(p, b, k0);                      // a multiple of the mask block, hence of TQ
+  const int ntiles = (p.Nq - qs) / TQ;
+  const int nqp = p.Nq;
+  const float* nl_g = p.delta + ((int64_t)b * p.H + hd) * nqp;
+  const float* nd_g = nl_g + (int64_t)p.B * p.H * nqp;
+  // The tile requests (LDS-DMA): per wave two 8-row groups of the Q image, two of the dO image and one row of statistics (waves 2, 3
+  // repeat the rows of waves 0, 1: same bytes to the same place, and every wave then has the same five requests per tile in flight).
+  // Address = wave-uniform 64-bit tile base (SGPR pair) + per-lane byte offset that never changes; the stream sets M0 itself.
+  unsigned vo[5];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+    const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+    vo[j] = (__umul24((unsigned)row, (unsigned)p.q_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+    vo[2 + j] = (__umul24((unsigned)row, (unsigned)p.o_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+  }
+  vo[4] = (unsigned)lane * 4u;
+  const float* st_g = (wave & 1) ? nd_g : nl_g;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 2048u);
+  const unsigned ldss = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * NS * IMG) + (unsigned)(wave & 1) * 256u);
+  auto tile_row = [&](int tt) { return qs + (tt < ntiles ? tt : ntiles - 1) * TQ; };      // past the end: the last tile again (never read)
+  auto q_base = [&](int tt) { return (uint64_t)(uintptr_t)(Qp + (int64_t)tile_row(tt) * p.q_rs); };
+  auto g_base = [&](int tt) { return (uint64_t)(uintptr_t)(Gp + (int64_t)tile_row(tt) * p.o_rs); };
+  auto s_base = [&](int tt) { return (uint64_t)(uintptr_t)(st_g + tile_row(tt)); };
+  // prologue: tiles 0 and 1 requested first, then this wave's K / V fragments (registers for the whole kernel); the wait for the
+  // fragments, placed by hipcc in front of the dummy use below, is in order and so covers the tiles too
+  if (ntiles > 0) {
+    dkdv_request_asm_slot0(vo, q_base(0), g_base(0), s_base(0), ldsw, ldss);
+    dkdv_request_asm_slot1(vo, q_base(1), g_base(1), s_base(1), ldsw, ldss);
+  }
   bf16x8 kfv[4], vfv[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     kfv[s] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)krow * p.k_rs + 16 * s + 8 * lh);
     vfv[s] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)krow * p.v_rs + 16 * s + 8 * lh);
   }
-  const int qs = q_first(p, b, k0);                      // a multiple of the mask block, hence of TQ
-  const int ntiles = (p.Nq - qs) / TQ;
-  const int nqp = p.Nq;
-  const float* nl_g = p.delta + ((int64_t)b * p.H + hd) * nqp;
-  const float* nd_g = nl_g + (int64_t)p.B * p.H * nqp;
-  auto request_tile = [&](int qb, int slot) __attribute__((always_inline)) {
-    dma_tile_bf16_d64<TQ, NW>(Qp, p.q_rs, qb, p.Nq, qimg(slot), wave, lane);
-    dma_tile_bf16_d64<TQ, NW>(Gp, p.o_rs, qb, p.Nq, gimg(slot), wave, lane);
-    if (wave < 2) {
-      const float* src = (wave == 0 ? nl_g : nd_g) + qb + lane;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(stats + slot * 2 * TQ + wave * TQ), 4, 0, 0);
-    }
-  };
-  if (ntiles > 0) {
-    request_tile(qs, 0);
-    if (ntiles > 1) request_tile(qs + TQ, 1);
-  }
-  auto wait_next = [&]() __attribute__((always_inline)) {
-    if (wave < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  if (ntiles > 1) wait_next(); else dma_wait_barrier();
   f32x16 dk[2], dv[2];
   zero_acc(dk);
   zero_acc(dv);
-  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
   unsigned aq[4], va0, va1;
 #pragma unroll
   for (int s_ = 0; s_ < 4; ++s_) aq[s_] = lds0 + (unsigned)Img<T, D>::off(li, (16 * s_ + 8 * lh) * 2);
@@ -1493,20 +1501,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_asm_kernel(AttnArgs p) {
     va1 = lds0 + (unsigned)(rpart + (((c0 ^ f0) ^ 4) << 4));
   }
   const unsigned ast = lds0 + (unsigned)(2 * NS * IMG) + (unsigned)lh * 16u;
-  for (int t = 0; t < ntiles; t += 3) {
-    if (t + 2 < ntiles) request_tile(qs + (t + 2) * TQ, 2);
-    dkdv_tile_asm_slot0(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast);
-    if (t + 2 < ntiles) wait_next(); else dma_wait_barrier();
-    if (t + 1 < ntiles) {
-      if (t + 3 < ntiles) request_tile(qs + (t + 3) * TQ, 0);
-      dkdv_tile_asm_slot1(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast);
-      if (t + 3 < ntiles) wait_next(); else dma_wait_barrier();
+  if (ntiles > 0) {
+    asm volatile("" ::"v"(kfv[0]), "v"(kfv[1]), "v"(kfv[2]), "v"(kfv[3]), "v"(vfv[0]), "v"(vfv[1]), "v"(vfv[2]), "v"(vfv[3]));
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // Each step: tile t from ring slot t % 3, with the requests of tile t + 2 issued from inside the stream and, at its end, the wait
+    // for tile t + 1 and the barrier.
+    for (int t = 0; t < ntiles; t += 3) {
+      dkdv_tile_asm_slot0(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast, vo, q_base(t + 2), g_base(t + 2), s_base(t + 2), ldsw, ldss);
+      if (t + 1 < ntiles) {
+        dkdv_tile_asm_slot1(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast, vo, q_base(t + 3), g_base(t + 3), s_base(t + 3), ldsw, ldss);
+      }
+      if (t + 2 < ntiles) {
+        dkdv_tile_asm_slot2(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast, vo, q_base(t + 4), g_base(t + 4), s_base(t + 4), ldsw, ldss);
+      }
     }
-    if (t + 2 < ntiles) {
-      if (t + 4 < ntiles) request_tile(qs + (t + 4) * TQ, 1);
-      dkdv_tile_asm_slot2(dk[0], dk[1], dv[0], dv[1], kfv, vfv, aq, va0, va1, ast);
-      if (t + 4 < ntiles) wait_next(); else dma_wait_barrier();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (unused) requests past the last tile have landed before the workgroup ends
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the stream's last MFMAs have retired before the compiler reads the accumulators
   T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
@@ -1571,7 +1580,7 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
       dim3 gq2((unsigned)(((a.Nq + NWQ * 32 - 1) / (NWQ * 32)) * a.H * a.B)), gk2((unsigned)(((a.Nk + NWK * 32 - 1) / (NWK * 32)) * a.H * a.B));
       allow_lds(attn_bwd_dq_ps_kernel<NWQ>, DQ_PS_LDS);
       hipLaunchKernelGGL(attn_bwd_dq_ps_kernel<NWQ>, gq2, dim3(NWQ * 64), DQ_PS_LDS, s, a);
-#ifdef FK_DKDV_ASM
+#ifndef FK_NO_DKDV_ASM
       // every tile of every workgroup fully visible and aligned -> the generated instruction stream
       const bool aligned = a.Nk % 128 == 0 && a.Nq % 64 == 0 && a.q_off == 0 && a.k_off == 0 &&
                            (a.mask_kind == FK_MASK_NONE || (a.mask_kind == FK_MASK_BLOCK_CAUSAL && a.mask_c % 128 == 0));

@@ -269,3 +269,15 @@ def test_bench_self_launch_dry_run_world2():
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "AssertionError" not in r.stderr
+
+
+def test_generated_dkdv_stream_is_current(tmp_path):
+    """frankenstein_amd/csrc/attn_dkdv_asm.inc is a build input that is committed: the generator reproduces it byte for byte."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    out = tmp_path / "gen.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FK_GEN_")}
+    subprocess.run([sys.executable, str(root / "tools" / "gen" / "gen_dkdv_asm.py"), str(out)], check=True, env=env, capture_output=True)
+    assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / "attn_dkdv_asm.inc").read_bytes()

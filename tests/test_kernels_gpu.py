@@ -258,6 +258,11 @@ PS_CASES = [
     (1, 2, 512, 512, 2, 256, 0.0),        # the benchmark's block size: no boundary tiles at all
     (1, 2, 640, 640, 2, 256, 40.0),       # a late key that outgrows reference 0 by far: lean loop -> fallback loop
     (1, 2, 384, 384, 2, 128, -3.0e3),     # every score hugely negative: the window test keeps the classic loop
+    # shapes the generated dK/dV stream takes (all tiles fully visible and aligned): 1 / 2 / 7 query tiles per key block (ring of 3)
+    (1, 2, 64, 128, 0, 0, 0.0),
+    (2, 1, 128, 256, 0, 0, 0.0),
+    (1, 3, 448, 128, 0, 0, 0.0),
+    (1, 2, 768, 768, 2, 128, 0.0),        # block-causal, 128-key blocks: 12, 10, .. 2 tiles
 ]
 
 

@@ -33,6 +33,7 @@ DP = [116, 148]
 ROW, TR, PK = 164, 196, 228
 LDS_PER_GAP = int(os.environ.get("FK_GEN_LDS_PER_GAP", "2"))
 VALU_UNITS = int(os.environ.get("FK_GEN_VALU_UNITS", "7"))       # issue budget of a gap in 4-cycle units (exp2 = 2)
+DMA_GAPS = [int(x) for x in os.environ.get("FK_GEN_DMA_GAPS", "2,6,10,14,18").split(",")]   # the gaps that carry the 5 LDS-DMA requests
 
 
 def vr(a, n=1):
@@ -62,6 +63,15 @@ class Model:
 
 def tr_reg(s, dt, w):
     return TR + 4 * ((s * 2 + dt) * 2 + w)
+
+
+def requests(ps):
+    """the five LDS-DMA requests of one wave for a tile going to ring slot ps: (set M0, load) pairs"""
+    return [(f"s_add_u32 m0, %[ldsw], {ps * IMG}", "global_load_lds_dwordx4 %[vo0], %[qb]"),
+            (f"s_add_u32 m0, %[ldsw], {ps * IMG + 1024}", "global_load_lds_dwordx4 %[vo1], %[qb]"),
+            (f"s_add_u32 m0, %[ldsw], {(NS + ps) * IMG}", "global_load_lds_dwordx4 %[vo2], %[gb]"),
+            (f"s_add_u32 m0, %[ldsw], {(NS + ps) * IMG + 1024}", "global_load_lds_dwordx4 %[vo3], %[gb]"),
+            (f"s_add_u32 m0, %[ldss], {ps * 2 * 64 * 4}", "global_load_lds_dword %[vo4], %[sb]")]
 
 
 def gen(slot):
@@ -153,6 +163,14 @@ def gen(slot):
             M.emit(v[0])
             units -= v[1]
 
+    # ------------------------------------------------------------------ the prefetch of tile t + 2 into ring slot (slot + 2) % 3
+    # (free since the barrier that ended the previous step): 2 KiB of the Q image, 2 KiB of the dO image and one row of statistics per
+    # wave.  Issued from inside the stream, one request every few MFMAs: the same five requests issued back to back after the barrier
+    # cost every wave ~1500 cycles of issue stall per tile (all eight waves of the CU queue up at the one address unit), 28 % of the kernel.
+    dma_at = dict(zip(DMA_GAPS, requests((slot + 2) % NS)))
+    if os.environ.get("FK_GEN_ABLATE_DMA"):                      # timing experiments only (wrong results)
+        dma_at = {}
+
     # gap 0: what the first two MFMAs need, nothing else (a long burst fills the LDS command queue and stalls the issue of everything behind it)
     issue_lds(0, 99, only_due=1)
     for g in range(1, 33):
@@ -174,9 +192,21 @@ def gen(slot):
         M.emit(text)
         if g == 1:
             issue_lds(1, 99, only_due=2)                        # the second MFMA's statistics and dO fragment
+        if g in dma_at:
+            M.emit(dma_at[g][0])
+        n0 = len(M.out)
         issue_lds(g, LDS_PER_GAP)
         issue_valu(g, VALU_UNITS)
+        if g in dma_at:
+            if len(M.out) == n0:
+                M.emit("s_nop 0")                               # one wait state between the write of M0 and the LDS-DMA that uses it
+            M.emit(dma_at[g][1])
     assert not lds_todo and not va_todo and not M.reads, (lds_todo.keys(), va_todo.keys(), M.reads)
+    # end of the step: the five requests of tile t + 1 (issued one step ago) have landed, this step's five may stay in flight; every wave
+    # is done reading this slot's images -> the barrier frees slot (slot + 2) % 3 ... of the NEXT step and publishes tile t + 1
+    M.emit("s_waitcnt vmcnt(5)")
+    if not os.environ.get("FK_GEN_ABLATE_BARRIER"):
+        M.emit("s_barrier")
     return M.out
 
 
@@ -188,14 +218,24 @@ def main():
         for slot in range(NS):
             ins = gen(slot)
             f.write(f"FK_DEV void dkdv_tile_asm_slot{slot}(f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4],\n"
-                    f"                                   const unsigned (&aq)[4], unsigned va0, unsigned va1, unsigned ast) {{\n")
+                    f"                                   const unsigned (&aq)[4], unsigned va0, unsigned va1, unsigned ast,\n"
+                    f"                                   const unsigned (&vo)[5], uint64_t qb, uint64_t gb, uint64_t sb, unsigned ldsw, unsigned ldss) {{\n")
             f.write("  asm volatile(\n")
             for i in ins:
                 f.write(f'      "{i}\\n\\t"\n')
             f.write('      : [dk0] "+v"(dk0), [dk1] "+v"(dk1), [dv0] "+v"(dv0), [dv1] "+v"(dv1)\n')
             f.write('      : [kf0] "v"(kf[0]), [kf1] "v"(kf[1]), [kf2] "v"(kf[2]), [kf3] "v"(kf[3]), [vf0] "v"(vf[0]), [vf1] "v"(vf[1]), [vf2] "v"(vf[2]), [vf3] "v"(vf[3]),\n')
-            f.write('        [aq0] "v"(aq[0]), [aq1] "v"(aq[1]), [aq2] "v"(aq[2]), [aq3] "v"(aq[3]), [va0] "v"(va0), [va1] "v"(va1), [ast] "v"(ast)\n')
-            f.write(f"      : {clob}, \"memory\");\n}}\n")
+            f.write('        [aq0] "v"(aq[0]), [aq1] "v"(aq[1]), [aq2] "v"(aq[2]), [aq3] "v"(aq[3]), [va0] "v"(va0), [va1] "v"(va1), [ast] "v"(ast),\n')
+            f.write('        [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [qb] "s"(qb), [gb] "s"(gb), [sb] "s"(sb), [ldsw] "s"(ldsw), [ldss] "s"(ldss)\n')
+            f.write(f"      : {clob}, \"m0\", \"scc\", \"memory\");\n}}\n")
+        # the same requests on their own (prologue: tiles 0 and 1), also as asm so that hipcc's wait-count pass never sees an LDS-DMA in
+        # this kernel (it would put a full vmcnt(0) in front of every block that may read LDS)
+        for slot in range(2):
+            f.write(f"FK_DEV void dkdv_request_asm_slot{slot}(const unsigned (&vo)[5], uint64_t qb, uint64_t gb, uint64_t sb, unsigned ldsw, unsigned ldss) {{\n  asm volatile(\n")
+            for m0, ld in requests(slot):
+                f.write(f'      "{m0}\\n\\t"\n      "s_nop 0\\n\\t"\n      "{ld}\\n\\t"\n')
+            f.write('      :\n      : [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [qb] "s"(qb), [gb] "s"(gb), [sb] "s"(sb), [ldsw] "s"(ldsw), [ldss] "s"(ldss)\n')
+            f.write('      : "m0", "scc", "memory");\n}\n')
         f.write(f"// instructions per tile step: {len(ins)}\n")
     print(f"{out}: {len(ins)} instructions per tile step")
 
