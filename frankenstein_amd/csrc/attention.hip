@@ -1253,6 +1253,102 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) 
     store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
 }
 
+#ifndef FK_NO_DQ_ASM
+#include "attn_dq_asm.inc"        // generated by tools/gen/gen_dq_asm.py: hand-placed instruction stream of one fully visible tile step
+// dQ for shapes where every tile of every wave is fully visible and aligned (launch_bwd checks): the tile step is the generated stream,
+// which also issues the K / V tile requests of the step after next and ends with the wait + barrier; the C++ around it is the prologue
+// (row statistics, delta, published for the dK/dV kernel exactly as attn_bwd_dq_ps_kernel does) and the store.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_asm_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64, NW = 4, BQ = NW * 32, IMG = BKV * 128, NS = 3;
+  static_assert(BKV == 64, "the generated stream is written for 64-key tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = p.Nq / BQ;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nqb), b = bh / p.H, hd = bh % p.H, q0 = (nqb - 1 - (int)(L % nqb)) * BQ;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const int qrow = q0 + wave * 32 + li;
+  const int ntiles = kv_limit(p, b, q0 + BQ - 1) / BKV;       // >= 1; every one of them fully visible to every row of the workgroup
+
+  // tile requests: per wave two 8-row groups of the K image and two of the V image; address = 64-bit tile base (SGPR pair) + per-lane
+  // byte offset that never changes
+  unsigned vo[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+    const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+    vo[j] = (__umul24((unsigned)row, (unsigned)p.k_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+    vo[2 + j] = (__umul24((unsigned)row, (unsigned)p.v_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 2048u);
+  auto tile_row = [&](int tt) { return (tt < ntiles ? tt : ntiles - 1) * BKV; };             // past the end: the last tile again (never read)
+  auto k_base = [&](int tt) { return (uint64_t)(uintptr_t)(Kp + (int64_t)tile_row(tt) * p.k_rs); };
+  auto v_base = [&](int tt) { return (uint64_t)(uintptr_t)(Vp + (int64_t)tile_row(tt) * p.v_rs); };
+  dq_request_asm_slot0(vo, k_base(0), v_base(0), ldsw);
+  dq_request_asm_slot1(vo, k_base(1), v_base(1), ldsw);
+
+  bf16x8 qf[4], gf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = *reinterpret_cast<const bf16x8*>(Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+    gf[s] = *reinterpret_cast<const bf16x8*>(Gp + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
+  }
+  const int64_t stat = ((int64_t)b * p.H + hd) * p.Nq + qrow;
+  const float lse2 = p.LSE[stat] * LOG2E;
+  float dl;
+  {
+    const T* Op = (const T*)p.O + (int64_t)b * p.o_bs + hd * D;
+    float part = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(Op + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += to_f32<T>(of[e]) * to_f32<T>(gf[s][e]);
+    }
+    dl = part + __shfl_xor(part, 32, 64);
+    if (lh == 0) {                                              // Nq is a multiple of 128 here: the workspace rows are Nq long
+      p.delta[stat] = -lse2;
+      p.delta[(int64_t)p.B * p.H * p.Nq + stat] = -dl;
+    }
+  }
+  f32x16 cl, cd;       // the row constants as initial accumulators: S' = Q'K^T - lse2, dP' = dO V^T - delta
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { cl[r] = -lse2; cd[r] = -dl; }
+  f32x16 dq[2];
+  zero_acc(dq);
+  unsigned aq[4], va0, va1;
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) aq[s_] = lds0 + (unsigned)Img<T, D>::off(li, (16 * s_ + 8 * lh) * 2);
+  {
+    const int g4 = lane >> 4, i16 = lane & 15, hh = g4 >> 1;
+    const int rpart = (4 * hh + (i16 >> 2)) * 128 + (i16 & 1) * 8;
+    const int c0 = 2 * (g4 & 1) + ((i16 & 3) >> 1), gg0 = 2 * hh + (i16 >> 3), f0 = gg0 ^ ((gg0 & 1) << 2);
+    va0 = lds0 + (unsigned)(rpart + ((c0 ^ f0) << 4));
+    va1 = lds0 + (unsigned)(rpart + (((c0 ^ f0) ^ 4) << 4));
+  }
+  // hipcc's wait for the register loads above goes in front of this use; it is in order and so covers the two tile requests too
+  asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(gf[0]), "v"(gf[1]), "v"(gf[2]), "v"(gf[3]), "v"(cl), "v"(cd));
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int t = 0; t < ntiles; t += 3) {
+    dq_tile_asm_slot0(dq[0], dq[1], qf, gf, cl, cd, aq, va0, va1, vo, k_base(t + 2), v_base(t + 2), ldsw);
+    if (t + 1 < ntiles) dq_tile_asm_slot1(dq[0], dq[1], qf, gf, cl, cd, aq, va0, va1, vo, k_base(t + 3), v_base(t + 3), ldsw);
+    if (t + 2 < ntiles) dq_tile_asm_slot2(dq[0], dq[1], qf, gf, cl, cd, aq, va0, va1, vo, k_base(t + 4), v_base(t + 4), ldsw);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // stray requests landed, the stream's last MFMAs retired
+  T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
+  if (p.rope_table)
+    store_rows_T_rope<T, D>(dQp, p.q_rs, qrow, true, dq, p.scale, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + qrow) * D);
+  else
+    store_rows_T<T, D>(dQp, p.q_rs, qrow, true, dq, p.scale, lh);
+}
+#endif
+
 #ifndef FK_NO_DKDV_ASM
 #include "attn_dkdv_asm.inc"      // generated by tools/gen/gen_dkdv_asm.py: hand-placed instruction stream of one fully visible tile step
 #endif
@@ -1578,13 +1674,22 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
     if (a.flags & FK_ATTN_Q_PRESCALED) {
       constexpr int NWQ = FK_DQ_NW, NWK = FK_DKDV_NW;
       dim3 gq2((unsigned)(((a.Nq + NWQ * 32 - 1) / (NWQ * 32)) * a.H * a.B)), gk2((unsigned)(((a.Nk + NWK * 32 - 1) / (NWK * 32)) * a.H * a.B));
-      allow_lds(attn_bwd_dq_ps_kernel<NWQ>, DQ_PS_LDS);
-      hipLaunchKernelGGL(attn_bwd_dq_ps_kernel<NWQ>, gq2, dim3(NWQ * 64), DQ_PS_LDS, s, a);
+      // every tile of every workgroup fully visible and aligned -> the generated instruction streams
+      const bool vis_all = a.q_off == 0 && a.k_off == 0 && (a.mask_kind == FK_MASK_NONE || (a.mask_kind == FK_MASK_BLOCK_CAUSAL && a.mask_c % 128 == 0));
+      bool dq_done = false;
+#ifndef FK_NO_DQ_ASM
+      if (vis_all && a.Nq % 128 == 0 && a.Nk % 64 == 0) {
+        allow_lds(attn_bwd_dq_asm_kernel, DQ_PS_LDS);
+        hipLaunchKernelGGL(attn_bwd_dq_asm_kernel, dim3((unsigned)(a.Nq / 128 * a.H * a.B)), dim3(256), DQ_PS_LDS, s, a);
+        dq_done = true;
+      }
+#endif
+      if (!dq_done) {
+        allow_lds(attn_bwd_dq_ps_kernel<NWQ>, DQ_PS_LDS);
+        hipLaunchKernelGGL(attn_bwd_dq_ps_kernel<NWQ>, gq2, dim3(NWQ * 64), DQ_PS_LDS, s, a);
+      }
 #ifndef FK_NO_DKDV_ASM
-      // every tile of every workgroup fully visible and aligned -> the generated instruction stream
-      const bool aligned = a.Nk % 128 == 0 && a.Nq % 64 == 0 && a.q_off == 0 && a.k_off == 0 &&
-                           (a.mask_kind == FK_MASK_NONE || (a.mask_kind == FK_MASK_BLOCK_CAUSAL && a.mask_c % 128 == 0));
-      if (aligned) {
+      if (vis_all && a.Nk % 128 == 0 && a.Nq % 64 == 0) {
         allow_lds(attn_bwd_dkdv_asm_kernel, DKDV_PS_LDS);
         hipLaunchKernelGGL(attn_bwd_dkdv_asm_kernel, gk2, dim3(256), DKDV_PS_LDS, s, a);
         return 0;

@@ -281,3 +281,14 @@ def test_generated_dkdv_stream_is_current(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.startswith("FK_GEN_")}
     subprocess.run([sys.executable, str(root / "tools" / "gen" / "gen_dkdv_asm.py"), str(out)], check=True, env=env, capture_output=True)
     assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / "attn_dkdv_asm.inc").read_bytes()
+
+
+def test_generated_dq_stream_is_current(tmp_path):
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    out = tmp_path / "gen.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FK_GEN_")}
+    subprocess.run([sys.executable, str(root / "tools" / "gen" / "gen_dq_asm.py"), str(out)], check=True, env=env, capture_output=True)
+    assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / "attn_dq_asm.inc").read_bytes()

@@ -263,6 +263,10 @@ PS_CASES = [
     (2, 1, 128, 256, 0, 0, 0.0),
     (1, 3, 448, 128, 0, 0, 0.0),
     (1, 2, 768, 768, 2, 128, 0.0),        # block-causal, 128-key blocks: 12, 10, .. 2 tiles
+    # and the generated dQ stream (128-query workgroups, 64-key tiles): 1 / 2 / 5 key tiles
+    (1, 2, 128, 64, 0, 0, 0.0),
+    (2, 1, 256, 128, 0, 0, 0.0),
+    (1, 2, 128, 320, 0, 0, 0.0),
 ]
 
 

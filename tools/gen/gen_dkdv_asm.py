@@ -27,6 +27,9 @@ have been issued.
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fkstream import vr, schedule, clobbers  # noqa: E402
+
 IMG, NS = 64 * 128, 3
 SC = [100, 132]
 DP = [116, 148]
@@ -34,31 +37,6 @@ ROW, TR, PK = 164, 196, 228
 LDS_PER_GAP = int(os.environ.get("FK_GEN_LDS_PER_GAP", "2"))
 VALU_UNITS = int(os.environ.get("FK_GEN_VALU_UNITS", "7"))       # issue budget of a gap in 4-cycle units (exp2 = 2)
 DMA_GAPS = [int(x) for x in os.environ.get("FK_GEN_DMA_GAPS", "2,6,10,14,18").split(",")]   # the gaps that carry the 5 LDS-DMA requests
-
-
-def vr(a, n=1):
-    return f"v{a}" if n == 1 else f"v[{a}:{a + n - 1}]"
-
-
-class Model:
-    def __init__(self):
-        self.out, self.reads, self.done = [], [], set()
-
-    def emit(self, s):
-        self.out.append(s)
-
-    def lds(self, rid, text):
-        self.reads.append(rid)
-        self.out.append(text)
-
-    def need(self, rids):
-        rids = [r for r in rids if r not in self.done]
-        if not rids:
-            return
-        last = max(self.reads.index(r) for r in rids)
-        self.out.append(f"s_waitcnt lgkmcnt({min(len(self.reads) - 1 - last, 15)})")
-        self.done.update(self.reads[:last + 1])
-        self.reads = self.reads[last + 1:]
 
 
 def tr_reg(s, dt, w):
@@ -77,7 +55,6 @@ def requests(ps):
 def gen(slot):
     qoff, soff = slot * IMG, slot * 2 * 64 * 4
     goff = qoff + NS * IMG
-    M = Model()
 
     # ------------------------------------------------------------------ the 32 MFMAs: (text, LDS reads needed, VALU results needed)
     mf = [None]
@@ -136,33 +113,6 @@ def gen(slot):
                                  18 + 8 * u + 4 * s, [("m", u, 8 * s + 2 * j), ("m", u, 8 * s + 2 * j + 1)])
     # the packed P / dS of half 1 overwrite row-fragment registers of k-steps 0 and 1, last read by MFMAs 11 / 12: free from gap 13 on (fine)
 
-    lds_todo = dict(lds)
-    va_todo = dict(va)
-    va_pos = {}
-
-    def issue_lds(gap, cap, only_due=None):
-        n = 0
-        while n < cap:
-            cands = [(v[2], k) for k, v in lds_todo.items() if v[1] <= gap and (only_due is None or v[2] <= only_due)]
-            if not cands:
-                break
-            _, k = min(cands)
-            M.lds(k, lds_todo.pop(k)[0])
-            n += 1
-
-    def issue_valu(gap, units):
-        while units > 0:
-            n = len(M.out)
-            cands = [(v[3], k) for k, v in va_todo.items()
-                     if v[2] <= gap and v[1] <= units and all(d in va_pos and n - va_pos[d] >= 2 for d in v[4])]
-            if not cands:
-                break
-            _, k = min(cands)
-            v = va_todo.pop(k)
-            va_pos[k] = len(M.out)
-            M.emit(v[0])
-            units -= v[1]
-
     # ------------------------------------------------------------------ the prefetch of tile t + 2 into ring slot (slot + 2) % 3
     # (free since the barrier that ended the previous step): 2 KiB of the Q image, 2 KiB of the dO image and one row of statistics per
     # wave.  Issued from inside the stream, one request every few MFMAs: the same five requests issued back to back after the barrier
@@ -171,48 +121,15 @@ def gen(slot):
     if os.environ.get("FK_GEN_ABLATE_DMA"):                      # timing experiments only (wrong results)
         dma_at = {}
 
-    # gap 0: what the first two MFMAs need, nothing else (a long burst fills the LDS command queue and stalls the issue of everything behind it)
-    issue_lds(0, 99, only_due=1)
-    for g in range(1, 33):
-        text, lneed, vneed = mf[g]
-        # late producers: VALU results this MFMA consumes must exist (and be 2 instructions old); flush them if the gaps did not fit them
-        missing = [k for k in vneed if k in va_todo]
-        while missing:
-            before = len(va_todo)
-            issue_valu(99, 99)
-            missing = [k for k in vneed if k in va_todo]
-            if len(va_todo) == before:
-                M.emit("s_nop 0")
-        while any(len(M.out) - va_pos[k] < 2 for k in vneed):
-            M.emit("s_nop 0")
-        for k in lneed:
-            if k in lds_todo:                                   # not released / scheduled in time: issue now
-                M.lds(k, lds_todo.pop(k)[0])
-        M.need(lneed)
-        M.emit(text)
-        if g == 1:
-            issue_lds(1, 99, only_due=2)                        # the second MFMA's statistics and dO fragment
-        if g in dma_at:
-            M.emit(dma_at[g][0])
-        n0 = len(M.out)
-        issue_lds(g, LDS_PER_GAP)
-        issue_valu(g, VALU_UNITS)
-        if g in dma_at:
-            if len(M.out) == n0:
-                M.emit("s_nop 0")                               # one wait state between the write of M0 and the LDS-DMA that uses it
-            M.emit(dma_at[g][1])
-    assert not lds_todo and not va_todo and not M.reads, (lds_todo.keys(), va_todo.keys(), M.reads)
     # end of the step: the five requests of tile t + 1 (issued one step ago) have landed, this step's five may stay in flight; every wave
     # is done reading this slot's images -> the barrier frees slot (slot + 2) % 3 ... of the NEXT step and publishes tile t + 1
-    M.emit("s_waitcnt vmcnt(5)")
-    if not os.environ.get("FK_GEN_ABLATE_BARRIER"):
-        M.emit("s_barrier")
-    return M.out
+    tail = ["s_waitcnt vmcnt(5)"] + ([] if os.environ.get("FK_GEN_ABLATE_BARRIER") else ["s_barrier"])
+    return schedule(mf, lds, va, dma_at, LDS_PER_GAP, VALU_UNITS, tail)
 
 
 def main():
     out = sys.argv[1]
-    clob = ", ".join(f'"v{r}"' for r in range(100, 244))
+    clob = clobbers(100, 244)
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen/gen_dkdv_asm.py - do not edit.  One fully visible dK/dV tile step per ring slot (see the generator's header).\n")
         for slot in range(NS):
@@ -227,7 +144,7 @@ def main():
             f.write('      : [kf0] "v"(kf[0]), [kf1] "v"(kf[1]), [kf2] "v"(kf[2]), [kf3] "v"(kf[3]), [vf0] "v"(vf[0]), [vf1] "v"(vf[1]), [vf2] "v"(vf[2]), [vf3] "v"(vf[3]),\n')
             f.write('        [aq0] "v"(aq[0]), [aq1] "v"(aq[1]), [aq2] "v"(aq[2]), [aq3] "v"(aq[3]), [va0] "v"(va0), [va1] "v"(va1), [ast] "v"(ast),\n')
             f.write('        [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [qb] "s"(qb), [gb] "s"(gb), [sb] "s"(sb), [ldsw] "s"(ldsw), [ldss] "s"(ldss)\n')
-            f.write(f"      : {clob}, \"m0\", \"scc\", \"memory\");\n}}\n")
+            f.write(f"      : {clob}, \"scc\", \"memory\");\n}}\n")
         # the same requests on their own (prologue: tiles 0 and 1), also as asm so that hipcc's wait-count pass never sees an LDS-DMA in
         # this kernel (it would put a full vmcnt(0) in front of every block that may read LDS)
         for slot in range(2):
@@ -235,7 +152,7 @@ def main():
             for m0, ld in requests(slot):
                 f.write(f'      "{m0}\\n\\t"\n      "s_nop 0\\n\\t"\n      "{ld}\\n\\t"\n')
             f.write('      :\n      : [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [qb] "s"(qb), [gb] "s"(gb), [sb] "s"(sb), [ldsw] "s"(ldsw), [ldss] "s"(ldss)\n')
-            f.write('      : "m0", "scc", "memory");\n}\n')
+            f.write('      : "scc", "memory");\n}\n')
         f.write(f"// instructions per tile step: {len(ins)}\n")
     print(f"{out}: {len(ins)} instructions per tile step")
 
