@@ -883,10 +883,15 @@ __device__ unsigned long long fk_stamp_acc[16];
 #define FK_ST_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define FK_ST(i) { const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; }
 #define FK_ST_FLUSH(base) if (lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&fk_stamp_acc[(base) + i_], st_acc[i_]); }
+// lifetime of every wave, summed per kernel (slot 8 + k): divided by wave slots x launch duration it gives the shader clock of the launch
+#define FK_LIFE_BEGIN const unsigned long long life_t0 = __builtin_amdgcn_s_memtime();
+#define FK_LIFE_END(k) if ((threadIdx.x & 63) == 0) atomicAdd(&fk_stamp_acc[8 + (k)], __builtin_amdgcn_s_memtime() - life_t0);
 #else
 #define FK_ST_DECL
 #define FK_ST(i)
 #define FK_ST_FLUSH(base)
+#define FK_LIFE_BEGIN
+#define FK_LIFE_END(k)
 #endif
 constexpr float PS_REDO = 1.0e12f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -1253,12 +1258,209 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) 
     store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
 }
 
+#ifndef FK_NO_FWD_ASM
+#include "attn_fwd_asm.inc"       // generated by tools/gen/gen_fwd_asm.py: hand-placed, software-pipelined lean forward tile steps
+// Forward for shapes where every tile of every wave is fully visible and aligned (launch_fwd checks).  Same algorithm as
+// attn_fwd_ps_kernel: classic online softmax until every row's maximum lies in the window, then reference 0 (P = exp2(S'), nothing else
+// per score) - here as generated instruction streams, one per 64-key tile, pipelined across tiles (the P.V products of a tile's second
+// half run in the next step).  The lean steps never branch: the largest half-row sum is tracked (rmax) and checked once at the end; if
+// any wave of the workgroup saw one above PS_REDO (a score far outside the window: precision / overflow risk), the WHOLE workgroup
+// redoes its rows with the classic loop.  Ring: 4 slots of 64 keys (K, V images), tile t + 2 requested during step t, one barrier per
+// step; every step of every wave, classic or lean, follows the same request / wait / barrier protocol.
+__global__ __launch_bounds__(256, 2) void attn_fwd_asm_kernel(AttnArgs p) {
+  FK_LIFE_BEGIN
+  using T = bf16_t;
+  constexpr int D = 64, NW = 4, BQ = NW * 32, IMG = BKV * 128, NS = 4;
+  static_assert(BKV == 64, "the generated streams are written for 64-key tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto kimg = [&](int i) -> char* { return smem + i * IMG; };
+  auto vimg = [&](int i) -> char* { return smem + (NS + i) * IMG; };
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = p.Nq / BQ;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nqb), b = bh / p.H, hd = bh % p.H, q0 = (nqb - 1 - (int)(L % nqb)) * BQ;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const int qrow = q0 + wave * 32 + li;
+  const int ntiles = kv_limit(p, b, q0 + BQ - 1) / BKV;       // >= 1; every one of them fully visible to every row of the workgroup
+
+  unsigned vo[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+    const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+    vo[j] = (__umul24((unsigned)row, (unsigned)p.k_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+    vo[2 + j] = (__umul24((unsigned)row, (unsigned)p.v_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 2048u);
+  auto tile_row = [&](int tt) { return (tt < ntiles ? tt : ntiles - 1) * BKV; };             // past the end: the last tile again (never read)
+  auto k_base = [&](int tt) { return (uint64_t)(uintptr_t)(Kp + (int64_t)tile_row(tt) * p.k_rs); };
+  auto v_base = [&](int tt) { return (uint64_t)(uintptr_t)(Vp + (int64_t)tile_row(tt) * p.v_rs); };
+  auto request = [&](int tt) __attribute__((always_inline)) {                                // tile tt -> slot tt % 4
+    switch (tt & 3) {
+      case 0: fwd_request_asm_slot0(vo, k_base(tt), v_base(tt), ldsw); break;
+      case 1: fwd_request_asm_slot1(vo, k_base(tt), v_base(tt), ldsw); break;
+      case 2: fwd_request_asm_slot2(vo, k_base(tt), v_base(tt), ldsw); break;
+      default: fwd_request_asm_slot3(vo, k_base(tt), v_base(tt), ldsw); break;
+    }
+  };
+  request(0);
+  request(1);
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+  unsigned aq[4], va0, va1;
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) aq[s_] = lds0 + (unsigned)Img<T, D>::off(li, (16 * s_ + 8 * lh) * 2);
+  {
+    const int g4 = lane >> 4, i16 = lane & 15, hh = g4 >> 1;
+    const int rpart = (4 * hh + (i16 >> 2)) * 128 + (i16 & 1) * 8;
+    const int c0 = 2 * (g4 & 1) + ((i16 & 3) >> 1), gg0 = 2 * hh + (i16 >> 3), f0 = gg0 ^ ((gg0 & 1) << 2);
+    va0 = lds0 + (unsigned)(rpart + ((c0 ^ f0) << 4));
+    va1 = lds0 + (unsigned)(rpart + (((c0 ^ f0) ^ 4) << 4));
+  }
+  // hipcc's wait for the Q fragments goes in front of this use; it is in order and so covers the two tile requests too
+  asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  float m = -INFINITY, l = 0.0f, rmax = 0.0f;
+  f32x16 o[2], sc1;
+  zero_acc(o);
+  // one tile with the classic running maximum, as a step of the ring protocol
+  auto classic_tile = [&](int t) __attribute__((always_inline)) {
+    request(t + 2);
+    const char* kt = kimg(t & 3);
+    const char* vt = vimg(t & 3);
+#pragma unroll 1
+    for (int u = 0; u < 2; ++u) {
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> kf, qq;
+        img_row<T, D>(kf, kt + u * 4096, li, s, lh);
+        qq.v = qf[s];
+        mma32<T>(sc, kf, qq);
+      }
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      if (__builtin_amdgcn_ballot_w64(tmax > m) != 0) {
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
+      const float mr = (m == -INFINITY) ? 0.0f : m;
+      float rs = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sc[r] - mr);
+        sc[r] = e;
+        rs += e;
+      }
+      l += rs;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag<T> pf;
+        frag_from_acc<T>(pf, sc, s);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          Frag<T> vf;
+          img_tr<T, D>(vf, vt + u * 4096, 0, s, 32 * dt, lane);
+          mma32<T>(o[dt], vf, pf);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+#define FK_FWD_STEP(KIND, tt)                                                                                                       \
+  switch ((tt) & 3) {                                                                                                               \
+    case 0: fwd_##KIND##_asm_slot0(o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw); break; \
+    case 1: fwd_##KIND##_asm_slot1(o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw); break; \
+    case 2: fwd_##KIND##_asm_slot2(o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw); break; \
+    default: fwd_##KIND##_asm_slot3(o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw); break; \
+  }
+
+  int* flag = reinterpret_cast<int*>(smem + 2 * NS * IMG);
+  bool lean_ok = true;                                         // workgroup-uniform
+  for (;;) {
+    int t = 0;
+    bool win = false;
+    // 1. classic until every row of the wave has a maximum inside the window in which reference 0 can neither overflow nor lose the row
+    for (; t < ntiles && !(win && lean_ok); ++t) {
+      classic_tile(t);
+      win = __builtin_amdgcn_ballot_w64(!(m >= -64.0f && m <= 32.0f)) == 0;
+    }
+    if (t < ntiles) {
+      // 2. re-reference to 0 and run the lean steps
+      const float a = __builtin_amdgcn_exp2f(m);
+      m = 0.0f;
+      l *= a;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc1[r] = 0.0f;
+      FK_FWD_STEP(first, t)
+      for (++t; t < ntiles && (t & 3) != 0; ++t) { FK_FWD_STEP(steady, t) }
+      // steady state without a switch (hipcc then keeps every operand in one place across the four step variants)
+#define FK_FWD_ARGS(tt) o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw
+      for (; t + 4 <= ntiles; t += 4) {                        // no branch inside: four steps back to back
+        fwd_steady_asm_slot0(FK_FWD_ARGS(t));
+        fwd_steady_asm_slot1(FK_FWD_ARGS(t + 1));
+        fwd_steady_asm_slot2(FK_FWD_ARGS(t + 2));
+        fwd_steady_asm_slot3(FK_FWD_ARGS(t + 3));
+      }
+      for (; t < ntiles; ++t) { FK_FWD_STEP(steady, t) }
+#undef FK_FWD_ARGS
+      FK_FWD_STEP(drain, t)                                    // slot argument: the last tile's slot + 1
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // stray requests landed, the last MFMAs retired
+    if (!lean_ok) break;
+    // 3. did any wave of the workgroup see a half-row sum outside the safe range?  (rare: then everything again, classic only)
+    const bool trip = __builtin_amdgcn_ballot_w64(!(rmax <= PS_REDO)) != 0;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    if (trip && lane == 0) *flag = 1;
+    __syncthreads();
+    if (*flag == 0) break;
+    lean_ok = false;
+    m = -INFINITY; l = 0.0f; rmax = 0.0f;
+    zero_acc(o);
+    __syncthreads();
+    request(0);
+    request(1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#undef FK_FWD_STEP
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+  T* Op = (T*)p.Out + (int64_t)b * p.o_bs + hd * D;
+  store_rows_T<T, D>(Op, p.o_rs, qrow, true, o, inv, lh);
+  if (lh == 0 && p.LSE) p.LSE[((int64_t)b * p.H + hd) * p.Nq + qrow] = lt > 0.0f ? m * LN2 + logf(lt) : INFINITY;
+  FK_LIFE_END(0)
+}
+constexpr size_t FWD_ASM_LDS = 2 * 4 * 64 * 128 + 16;
+#endif
+
 #ifndef FK_NO_DQ_ASM
 #include "attn_dq_asm.inc"        // generated by tools/gen/gen_dq_asm.py: hand-placed instruction stream of one fully visible tile step
 // dQ for shapes where every tile of every wave is fully visible and aligned (launch_bwd checks): the tile step is the generated stream,
 // which also issues the K / V tile requests of the step after next and ends with the wait + barrier; the C++ around it is the prologue
 // (row statistics, delta, published for the dK/dV kernel exactly as attn_bwd_dq_ps_kernel does) and the store.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_asm_kernel(AttnArgs p) {
+  FK_LIFE_BEGIN
   using T = bf16_t;
   constexpr int D = 64, NW = 4, BQ = NW * 32, IMG = BKV * 128, NS = 3;
   static_assert(BKV == 64, "the generated stream is written for 64-key tiles");
@@ -1346,6 +1548,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_asm_kernel(AttnArgs p) {
     store_rows_T_rope<T, D>(dQp, p.q_rs, qrow, true, dq, p.scale, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + qrow) * D);
   else
     store_rows_T<T, D>(dQp, p.q_rs, qrow, true, dq, p.scale, lh);
+  FK_LIFE_END(1)
 }
 #endif
 
@@ -1530,6 +1733,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
 // is kept small on purpose: the stream owns v100-v243, the compiler the remaining 112 registers (dK/dV accumulators 64, K/V fragments 32,
 // seven LDS addresses).
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_asm_kernel(AttnArgs p) {
+  FK_LIFE_BEGIN
   using T = bf16_t;
   constexpr int D = 64, TQ = 64, BK = 128, NW = 4, IMG = TQ * 128, NS = 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1621,6 +1825,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_asm_kernel(AttnArgs p) {
   else
     store_rows_T<T, D>(dKp, p.k_rs, krow, true, dk, LN2, lh);
   store_rows_T<T, D>(dVp, p.v_rs, krow, true, dv, 1.0f, lh);
+  FK_LIFE_END(2)
 }
 #endif
 
@@ -1649,6 +1854,15 @@ template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
   constexpr int NW = Img<T, D>::SWZ ? 8 : 4;
   if constexpr (Img<T, D>::SWZ) {
     if (a.flags & FK_ATTN_Q_PRESCALED) {
+#ifndef FK_NO_FWD_ASM
+      // every tile of every workgroup fully visible and aligned -> the generated instruction streams
+      if (a.q_off == 0 && a.k_off == 0 && (a.mask_kind == FK_MASK_NONE || (a.mask_kind == FK_MASK_BLOCK_CAUSAL && a.mask_c % 128 == 0)) &&
+          a.Nq % 128 == 0 && a.Nk % 64 == 0) {
+        allow_lds(attn_fwd_asm_kernel, FWD_ASM_LDS);
+        hipLaunchKernelGGL(attn_fwd_asm_kernel, dim3((unsigned)(a.Nq / 128 * a.H * a.B)), dim3(256), FWD_ASM_LDS, s, a);
+        return 0;
+      }
+#endif
       constexpr int NWF = FK_FWD_NW;
       dim3 grid((unsigned)(((a.Nq + NWF * 32 - 1) / (NWF * 32)) * a.H * a.B));
       const size_t lds = fwd_lds<T, D>();

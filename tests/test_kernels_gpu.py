@@ -267,6 +267,15 @@ PS_CASES = [
     (1, 2, 128, 64, 0, 0, 0.0),
     (2, 1, 256, 128, 0, 0, 0.0),
     (1, 2, 128, 320, 0, 0, 0.0),
+    # the generated forward streams: warm-up tile + first / steady / drain steps at every ring phase (2 .. 9 tiles), and a late spike that
+    # must send the whole workgroup back through the classic loop
+    (1, 1, 128, 128, 0, 0, 0.0),
+    (1, 2, 128, 192, 0, 0, 0.0),
+    (1, 2, 256, 384, 0, 0, 0.0),
+    (1, 1, 128, 448, 0, 0, 0.0),
+    (1, 2, 128, 576, 0, 0, 0.0),
+    (1, 2, 1024, 1024, 2, 256, 0.0),
+    (1, 2, 768, 768, 0, 0, 40.0),
 ]
 
 
@@ -315,7 +324,7 @@ def test_attention_prescaled_q(K, case):
     # the two forms of the same problem agree with each other at bf16 rounding level
     qun = dev(qr.detach().reshape(B, Nq, H, D), dtype)
     o2, lse2 = K.attn_fwd(qun, kd, vd, m)
-    assert float((o2.float() - o.float()).abs().max()) < 6e-2
+    assert float((o2.float() - o.float()).abs().max()) < 6e-2 * max(1.0, float(o.float().abs().max()) / 4)    # two bf16 ulps of the largest output
 
 
 def test_attention_prescaled_q_masks_from_tables(K):

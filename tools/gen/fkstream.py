@@ -10,6 +10,9 @@ and one more have been issued.
 """
 
 
+import os
+
+
 def vr(a, n=1):
     return f"v{a}" if n == 1 else f"v[{a}:{a + n - 1}]"
 
@@ -30,7 +33,8 @@ class Model:
         if not rids:
             return
         last = max(self.reads.index(r) for r in rids)
-        self.out.append(f"s_waitcnt lgkmcnt({min(len(self.reads) - 1 - last, 15)})")
+        if not os.environ.get("FK_GEN_ABLATE_LGKM"):            # timing experiments only (wrong results): no waits for LDS reads
+            self.out.append(f"s_waitcnt lgkmcnt({min(len(self.reads) - 1 - last, 15)})")
         self.done.update(self.reads[:last + 1])
         self.reads = self.reads[last + 1:]
 
@@ -98,9 +102,19 @@ def schedule(mf, lds, va, dma_at, lds_per_gap, valu_units, tail):
             if len(M.out) == n0:
                 M.emit("s_nop 0")                               # one wait state between the write of M0 and the LDS-DMA that uses it
             M.emit(dma_at[g][1])
+    while va_todo:                                              # work without a consumer inside the step (results carried to the next one)
+        before = len(va_todo)
+        issue_valu(99, 99)
+        if len(va_todo) == before:
+            M.emit("s_nop 0")
     assert not lds_todo and not va_todo and not M.reads, (lds_todo.keys(), va_todo.keys(), M.reads)
     for t in tail:
         M.emit(t)
+    # timing experiments only (wrong results): leave out one class of instructions
+    drop = [pre for flag, pre in (("FK_GEN_ABLATE_VALU", ("v_exp", "v_add", "v_mul", "v_max", "v_cvt", "v_pk")), ("FK_GEN_ABLATE_LDS", ("ds_read",)),
+                                   ("FK_GEN_ABLATE_MFMA", ("v_mfma",)), ("FK_GEN_ABLATE_EXP", ("v_exp",))) if os.environ.get(flag)]
+    for pre in drop:
+        M.out = [i for i in M.out if not i.startswith(pre)]
     return M.out
 
 
