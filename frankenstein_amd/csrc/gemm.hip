@@ -172,6 +172,18 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
       const int bb = mb / p.rope_T, dd = nb % p.rope_D;
       tb = rope_table + (nb < p.rope_qcols ? p.rope_qoff : (int64_t)0) + (int64_t)bb * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + dd / 2) * 2;
     }
+    // Output / auxiliary row pointers advance by 8 rows per pass: computed once here (a 64-bit multiply per pointer and pass is 5
+    // quarter-rate VALU instructions, and the sweep is VALU-bound: they were a quarter of the fused SwiGLU epilogue)
+    TO* cp_run = C + (int64_t)mb * p.ldc + nb;
+    const int64_t cp_step = 8 * p.ldc;
+    char* aux_run = nullptr;               // mode 1: g row (T, column nb / 2); mode 2: h13 row (T, column 2 nb), dh13 row = C (T, column 2 nb)
+    int64_t aux_step = 0;
+    T* dp_run = nullptr;
+    if (mode == 1) { aux_run = (char*)((T*)p.aux + (int64_t)mb * p.ldaux + (nb >> 1)); aux_step = 8 * p.ldaux * (int64_t)sizeof(T); }
+    if (mode == 2) {
+      aux_run = (char*)((T*)p.aux + (int64_t)mb * p.ldaux + 2 * nb); aux_step = 8 * p.ldaux * (int64_t)sizeof(T);
+      dp_run = (T*)p.C + (int64_t)mb * p.ldc + 2 * nb;
+    }
 #pragma unroll SWEEP_UNROLL
     for (int ps = 0; ps < 4 * NI; ++ps) {
       const int row = ps * 8 + r0, m = mrow0 + row;
@@ -216,8 +228,8 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
           // SwiGLU backward fused into the down-projection dgrad: v = dg[m, nb..nb+7]; h13 / dh13 use the interleaved hidden
           // layout (per 4 hidden units: 4 x h1 then 4 x h3), so the 8 units of this lane are 16 contiguous columns.
           if constexpr (sizeof(TO) == sizeof(T)) {
-            const T* hp = (const T*)p.aux + (int64_t)m * p.ldaux + 2 * nb;
-            T* dp = (T*)p.C + (int64_t)m * p.ldc + 2 * nb;
+            const T* hp = (const T*)aux_run;
+            T* dp = dp_run;
             float hv[16], ov[16];
             if constexpr (PAUX) {
 #pragma unroll
@@ -256,7 +268,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
             }
           }
         } else {
-          TO* cp = C + (int64_t)m * p.ldc + nb;
+          TO* cp = cp_run;
           if constexpr (sizeof(TO) == 2) {
             bf16x8 o8;
 #pragma unroll
@@ -269,7 +281,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
           if (mode == 1) {
             // SwiGLU forward fused into the up-projection: the 8 columns are (h1[4], h3[4]) of 4 hidden units
             if constexpr (sizeof(TO) == sizeof(T)) {
-              T* gp = (T*)p.aux + (int64_t)m * p.ldaux + (nb >> 1);
+              T* gp = (T*)aux_run;
               float gq[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) gq[e] = v[e] * sigmoid_f<T>(v[e]) * v[4 + e];
@@ -286,6 +298,9 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
         }
       }
       // advance the row-dependent cursors by 8 rows
+      cp_run += cp_step;
+      aux_run += aux_step;
+      if (mode == 2) dp_run += cp_step;
       if (res) {
         if constexpr (PRE) {
           rq0 = rq1; rq1 = rq2; rq2 = rq3;             // next pass's prefetched row
@@ -702,12 +717,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
     const int done = slot == 0 ? NS - 1 : slot - 1;  // slot of the tile's last stage: the staging area once every wave has read it
     asm volatile("s_barrier" ::: "memory");
     char* stg = wave < R::IN_SLOT ? smem + done * STAGE + wave * 8192 : smem + NS * STAGE + (wave - R::IN_SLOT) * 8192;
+#ifdef FK_RING_PROBE_NOEPI          // probe builds: main loops only (one store per tile keeps the accumulators alive)
+    if (acc[0][0][0] == 123.456f) ((float*)p.C)[tid] = acc[MT - 1][1][3];
+#else
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
       if (EPI == 0 && BN_ == 128 && p.res) nt_epilogue<T, TO, true, 1, true, EPI>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
       else nt_epilogue<T, TO, true, 1, false, EPI>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
     }
+#endif
   }
 }
 
@@ -811,11 +830,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
     }
     asm volatile("s_barrier" ::: "memory");          // every wave has read the last stage: its two slots become the staging area
     char* stg = wave < 4 ? aslot(sa == 0 ? 2 : sa - 1) + wave * 8192 : bslot(sb ^ 1) + (wave - 4) * 8192;
+#ifdef FK_RING_PROBE_NOEPI
+    if (acc[0][0][0] == 123.456f) ((float*)p.C)[tid] = acc[MT - 1][1][3];
+#else
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
       nt_epilogue<T, TO, true, 1, false, EPI>(p, sub, stg, m0 + wm * WM + i * 32, n0 + wn * 64, lane, false);
     }
+#endif
   }
 }
 

@@ -321,10 +321,12 @@ def test_attention_prescaled_q(K, case):
     close(dq, qr.grad, dtype, atol16=4e-2 * max(1.0, float(qr.grad.abs().max()) / 4))       # (the spike case has |dq|, |dk| >> 1)
     close(dk, kr.grad, dtype, atol16=4e-2 * max(1.0, float(kr.grad.abs().max()) / 4))
     close(dv, vr.grad, dtype, atol16=4e-2)
-    # the two forms of the same problem agree with each other at bf16 rounding level
-    qun = dev(qr.detach().reshape(B, Nq, H, D), dtype)
-    o2, lse2 = K.attn_fwd(qun, kd, vd, m)
-    assert float((o2.float() - o.float()).abs().max()) < 6e-2 * max(1.0, float(o.float().abs().max()) / 4)    # two bf16 ulps of the largest output
+    # the two forms of the same problem agree with each other at bf16 rounding level (not the spiked ones: Q' and q round differently,
+    # and a score of several hundred turns that 2^-8 relative difference into a different softmax)
+    if spike == 0:
+        qun = dev(qr.detach().reshape(B, Nq, H, D), dtype)
+        o2, lse2 = K.attn_fwd(qun, kd, vd, m)
+        assert float((o2.float() - o.float()).abs().max()) < 6e-2
 
 
 def test_attention_prescaled_q_masks_from_tables(K):
