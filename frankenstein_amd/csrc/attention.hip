@@ -904,6 +904,7 @@ FK_DEV void dma_wait_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
+  FK_LIFE_BEGIN
   using T = bf16_t;
   constexpr int D = 64, BQ = NW * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1096,6 +1097,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
   store_rows_T<T, D>(Op, p.o_rs, qrow, q_ok, o, inv, lh);
   if (q_ok && lh == 0 && p.LSE)
     p.LSE[((int64_t)b * p.H + hd) * p.Nq + qrow] = lt > 0.0f ? m * LN2 + logf(lt) : INFINITY;
+  FK_LIFE_END(0)
 }
 
 // ------------------------------------------------------------------------------------------------- dQ (pre-scaled Q)
@@ -1449,7 +1451,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_asm_kernel(AttnArgs p) {
   T* Op = (T*)p.Out + (int64_t)b * p.o_bs + hd * D;
   store_rows_T<T, D>(Op, p.o_rs, qrow, true, o, inv, lh);
   if (lh == 0 && p.LSE) p.LSE[((int64_t)b * p.H + hd) * p.Nq + qrow] = lt > 0.0f ? m * LN2 + logf(lt) : INFINITY;
-  FK_LIFE_END(0)
+  FK_LIFE_END(3)
 }
 constexpr size_t FWD_ASM_LDS = 2 * 4 * 64 * 128 + 16;
 #endif

@@ -271,24 +271,14 @@ def test_bench_self_launch_dry_run_world2():
         assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "AssertionError" not in r.stderr
 
 
-def test_generated_dkdv_stream_is_current(tmp_path):
-    """frankenstein_amd/csrc/attn_dkdv_asm.inc is a build input that is committed: the generator reproduces it byte for byte."""
+@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd"])
+def test_generated_streams_are_current(tmp_path, gen):
+    """frankenstein_amd/csrc/attn_*_asm.inc are build inputs that are committed: the generators (tools/gen) reproduce them byte for byte."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     out = tmp_path / "gen.inc"
     env = {k: v for k, v in os.environ.items() if not k.startswith("FK_GEN_")}
-    subprocess.run([sys.executable, str(root / "tools" / "gen" / "gen_dkdv_asm.py"), str(out)], check=True, env=env, capture_output=True)
-    assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / "attn_dkdv_asm.inc").read_bytes()
-
-
-def test_generated_dq_stream_is_current(tmp_path):
-    import subprocess
-    import sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parents[1]
-    out = tmp_path / "gen.inc"
-    env = {k: v for k, v in os.environ.items() if not k.startswith("FK_GEN_")}
-    subprocess.run([sys.executable, str(root / "tools" / "gen" / "gen_dq_asm.py"), str(out)], check=True, env=env, capture_output=True)
-    assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / "attn_dq_asm.inc").read_bytes()
+    subprocess.run([sys.executable, str(root / "tools" / "gen" / f"gen_{gen}_asm.py"), str(out)], check=True, env=env, capture_output=True)
+    assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / f"attn_{gen}_asm.inc").read_bytes()
