@@ -1554,6 +1554,112 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_asm_kernel(AttnArgs p) {
 }
 #endif
 
+#ifdef FK_DQ16_ASM
+#include "attn_dq16_asm.inc"      // generated by tools/gen/gen_dq16_asm.py: the dQ tile step on v_mfma_f32_16x16x32_bf16
+// Same contract as attn_bwd_dq_asm_kernel (shapes, workspace rows for the dK/dV kernel), fragments and accumulators in the layouts of the
+// 16x16x32 MFMA: lane = (c, g) = (lane % 16, lane / 16); query blocks qb of 16 rows, d in 16-byte chunks 4 ks + tau(g), tau = [0, 3, 1, 2].
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq16_asm_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64, NW = 4, BQ = NW * 32, IMG = BKV * 128, NS = 3;
+  static_assert(BKV == 64, "the generated stream is written for 64-key tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = p.Nq / BQ;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nqb), b = bh / p.H, hd = bh % p.H, q0 = (nqb - 1 - (int)(L % nqb)) * BQ;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const T* Op = (const T*)p.O + (int64_t)b * p.o_bs + hd * D;
+  const int ntiles = kv_limit(p, b, q0 + BQ - 1) / BKV;
+  const int tau = (0x2130 >> (4 * g)) & 3;                        // d-chunk of lane group g within a k-step: 0, 3, 1, 2
+
+  unsigned vo[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+    const int gg = (row >> 1) & 7, f = gg ^ ((gg & 1) << 2);
+    vo[j] = (__umul24((unsigned)row, (unsigned)p.k_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+    vo[2 + j] = (__umul24((unsigned)row, (unsigned)p.v_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 2048u);
+  auto tile_row = [&](int tt) { return (tt < ntiles ? tt : ntiles - 1) * BKV; };
+  auto k_base = [&](int tt) { return (uint64_t)(uintptr_t)(Kp + (int64_t)tile_row(tt) * p.k_rs); };
+  auto v_base = [&](int tt) { return (uint64_t)(uintptr_t)(Vp + (int64_t)tile_row(tt) * p.v_rs); };
+  dq_request_asm_slot0(vo, k_base(0), v_base(0), ldsw);
+  dq_request_asm_slot1(vo, k_base(1), v_base(1), ldsw);
+
+  bf16x8 qf[2][2], gf[2][2];
+  f32x4 cl[2], cd[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = q0 + wave * 32 + 16 * qb + c;
+    float part = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int d0 = 32 * ks + 8 * tau;
+      qf[qb][ks] = *reinterpret_cast<const bf16x8*>(Qp + (int64_t)qrow * p.q_rs + d0);
+      gf[qb][ks] = *reinterpret_cast<const bf16x8*>(Gp + (int64_t)qrow * p.o_rs + d0);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(Op + (int64_t)qrow * p.o_rs + d0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += to_f32<T>(of[e]) * to_f32<T>(gf[qb][ks][e]);
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);                           // delta = rowsum(dO * O) over the four lane groups
+    const int64_t stat = ((int64_t)b * p.H + hd) * p.Nq + qrow;
+    const float lse2 = p.LSE[stat] * LOG2E;
+    if (g == 0) {
+      p.delta[stat] = -lse2;
+      p.delta[(int64_t)p.B * p.H * p.Nq + stat] = -part;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cl[qb][r] = -lse2; cd[qb][r] = -part; }
+  }
+  f32x4 dq[4][2];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) dq[db][qb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  unsigned aq[2], va[4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) aq[ks] = lds0 + (unsigned)Img<T, D>::off(c, (4 * ks + tau) * 16);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) va[db] = lds0 + (unsigned)Img<T, D>::off(4 * g + (c >> 2), (16 * db + 4 * (c & 3)) * 2);
+  asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]), "v"(gf[0][0]), "v"(gf[0][1]), "v"(gf[1][0]), "v"(gf[1][1]),
+               "v"(cl[0]), "v"(cl[1]), "v"(cd[0]), "v"(cd[1]));
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int t = 0; t < ntiles; t += 3) {
+    dq16_tile_asm_slot0(dq, qf, gf, cl, cd, aq, va, vo, k_base(t + 2), v_base(t + 2), ldsw);
+    if (t + 1 < ntiles) dq16_tile_asm_slot1(dq, qf, gf, cl, cd, aq, va, vo, k_base(t + 3), v_base(t + 3), ldsw);
+    if (t + 2 < ntiles) dq16_tile_asm_slot2(dq, qf, gf, cl, cd, aq, va, vo, k_base(t + 4), v_base(t + 4), ldsw);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  // store: block (db, qb) of this lane = dQ[query 16 qb + c][d = 16 db + 4 g .. + 3]
+  T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = q0 + wave * 32 + 16 * qb + c;
+    const float* table = p.rope_table ? p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + qrow) * D : nullptr;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const int d = 16 * db + 4 * g;
+      const float a0 = dq[db][qb][0] * p.scale, a1 = dq[db][qb][1] * p.scale, a2 = dq[db][qb][2] * p.scale, a3 = dq[db][qb][3] * p.scale;
+      float o0 = a0, o1 = a1, o2 = a2, o3 = a3;
+      if (table) {                                              // inverse RoPE: pairs (d, d + 1) rotated by -angle, as store_rows_T_rope
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(table + d);
+        o0 = a0 * cs[0] + a1 * cs[1]; o1 = -a0 * cs[1] + a1 * cs[0];
+        o2 = a2 * cs[2] + a3 * cs[3]; o3 = -a2 * cs[3] + a3 * cs[2];
+      }
+      const bf16x4 v = {(bf16_t)o0, (bf16_t)o1, (bf16_t)o2, (bf16_t)o3};
+      *reinterpret_cast<bf16x4*>(dQp + (int64_t)qrow * p.q_rs + d) = v;
+    }
+  }
+}
+#endif
+
 #ifndef FK_NO_DKDV_ASM
 #include "attn_dkdv_asm.inc"      // generated by tools/gen/gen_dkdv_asm.py: hand-placed instruction stream of one fully visible tile step
 #endif
@@ -1895,8 +2001,13 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
       bool dq_done = false;
 #ifndef FK_NO_DQ_ASM
       if (vis_all && a.Nq % 128 == 0 && a.Nk % 64 == 0) {
+#ifdef FK_DQ16_ASM
+        allow_lds(attn_bwd_dq16_asm_kernel, DQ_PS_LDS);
+        hipLaunchKernelGGL(attn_bwd_dq16_asm_kernel, dim3((unsigned)(a.Nq / 128 * a.H * a.B)), dim3(256), DQ_PS_LDS, s, a);
+#else
         allow_lds(attn_bwd_dq_asm_kernel, DQ_PS_LDS);
         hipLaunchKernelGGL(attn_bwd_dq_asm_kernel, dim3((unsigned)(a.Nq / 128 * a.H * a.B)), dim3(256), DQ_PS_LDS, s, a);
+#endif
         dq_done = true;
       }
 #endif

@@ -271,7 +271,7 @@ def test_bench_self_launch_dry_run_world2():
         assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "AssertionError" not in r.stderr
 
 
-@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd"])
+@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd", "dq16"])
 def test_generated_streams_are_current(tmp_path, gen):
     """frankenstein_amd/csrc/attn_*_asm.inc are build inputs that are committed: the generators (tools/gen) reproduce them byte for byte."""
     import subprocess
