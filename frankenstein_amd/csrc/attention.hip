@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) 
     store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
 }
 
-#ifdef FK_FWD_ASM                 // opt-in build (-DFK_FWD_ASM): measured no faster than attn_fwd_ps_kernel, kept for the record
+#ifndef FK_NO_FWD_ASM
 #include "attn_fwd_asm.inc"       // generated by tools/gen/gen_fwd_asm.py: hand-placed, software-pipelined lean forward tile steps
 // Forward for shapes where every tile of every wave is fully visible and aligned (launch_fwd checks).  Same algorithm as
 // attn_fwd_ps_kernel: classic online softmax until every row's maximum lies in the window, then reference 0 (P = exp2(S'), nothing else
@@ -1962,7 +1962,7 @@ template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
   constexpr int NW = Img<T, D>::SWZ ? 8 : 4;
   if constexpr (Img<T, D>::SWZ) {
     if (a.flags & FK_ATTN_Q_PRESCALED) {
-#ifdef FK_FWD_ASM
+#ifndef FK_NO_FWD_ASM
       // every tile of every workgroup fully visible and aligned -> the generated instruction streams
       if (a.q_off == 0 && a.k_off == 0 && (a.mask_kind == FK_MASK_NONE || (a.mask_kind == FK_MASK_BLOCK_CAUSAL && a.mask_c % 128 == 0)) &&
           a.Nq % 128 == 0 && a.Nk % 64 == 0) {

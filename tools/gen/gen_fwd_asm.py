@@ -127,9 +127,11 @@ def gen(slot, kind):
     if cur:
         gaps = [2, 5, 8, 11] if prev else [2, 4, 7, 10]
         dma_at = dict(zip(gaps, requests((slot + 2) % NS)))
+        if os.environ.get("FK_GEN_ABLATE_DMA"):                  # timing experiments only (wrong results)
+            dma_at = {}
         # end of the step: tile i + 1 (requested one step ago) has landed, this step's requests stay in flight; the barrier publishes it and
         # says every wave is done with tile i - 1's slot (the one the NEXT step's requests overwrite)
-        tail = ["s_waitcnt vmcnt(4)", "s_barrier"]
+        tail = ["s_waitcnt vmcnt(4)"] + ([] if os.environ.get("FK_GEN_ABLATE_BARRIER") else ["s_barrier"])
     return schedule(mf, lds, va, dma_at, LDS_PER_GAP, VALU_UNITS, tail)
 
 
