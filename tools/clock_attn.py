@@ -24,10 +24,10 @@ def timed(f, n=5):
     for _ in range(n): f()
     b.record(); torch.cuda.synchronize()
     lib.fk_debug_stamps(buf, 1)
-    return a.elapsed_time(b) / n, [x / n for x in buf[8:11]]
+    return a.elapsed_time(b) / n, [x / n for x in buf[8:12]]
 slots = 256 * 8                                                   # backward: 2 workgroups x 4 waves per CU
-fslots = 256 * 16                                                 # forward (attn_fwd_ps_kernel): 2 workgroups x 8 waves per CU
+fslots = 256 * 8                                                  # forward (attn_fwd_asm_kernel): 2 workgroups x 4 waves per CU
 ms, life = timed(lambda: K.attn_fwd(q, k, v, mask, q_prescaled=True))
-print(f"fwd : {ms:.3f} ms, wave lifetimes {life[0] / 1e9:.3f} G ticks -> {life[0] / fslots / (ms * 1e3):.0f} MHz if every slot is always occupied")
+print(f"fwd : {ms:.3f} ms, wave lifetimes {(life[0] + life[3]) / 1e9:.3f} G ticks -> {(life[0] + life[3]) / fslots / (ms * 1e3):.0f} MHz if every slot is always occupied")
 ms, life = timed(lambda: K.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, mask, q_prescaled=True))
 print(f"bwd : {ms:.3f} ms (dQ + dK/dV), lifetimes dQ {life[1] / 1e9:.3f} G, dK/dV {life[2] / 1e9:.3f} G ticks -> {(life[1] + life[2]) / slots / (ms * 1e3):.0f} MHz")
