@@ -1416,7 +1416,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_asm_kernel(AttnArgs p) {
       for (int r = 0; r < 16; ++r) sc1[r] = 0.0f;
       FK_FWD_STEP(first, t)
       for (++t; t < ntiles && (t & 3) != 0; ++t) { FK_FWD_STEP(steady, t) }
-      // steady state without a switch (hipcc then keeps every operand in one place across the four step variants)
+      // steady state without a switch (hipcc then keeps every operand in one place across the four step variants).  Told here that
+      // nothing of ITS memory traffic is pending (spill stores of the classic phase are vector-memory operations): otherwise its wait-count
+      // pass puts a vmcnt(0) at the head of the loop below, which drains the streams' tile requests every fourth step.
+      __builtin_amdgcn_s_waitcnt(0x0F70);
 #define FK_FWD_ARGS(tt) o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw
       for (; t + 4 <= ntiles; t += 4) {                        // no branch inside: four steps back to back
         fwd_steady_asm_slot0(FK_FWD_ARGS(t));
