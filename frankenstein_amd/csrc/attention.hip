@@ -485,6 +485,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ================================================================================================= dQ
+// Tile hand-over of the backward kernels: on the LDS-DMA path a wave's own requests (and its LDS stores) must have landed BEFORE it joins
+// the barrier — every wave reads rows that other waves requested, and a wait placed after the barrier covers only the wave's own.
+template <bool DMA> FK_DEV void tile_sync() {
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
 template <typename T, int D>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   using C = AT<T, D>;
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
       sv.store(vimg(0), C::RSTRIDE, tid);
     }
   }
-  __syncthreads();
+  tile_sync<DMA>();
 
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see attn_fwd_kernel
   const float c = p.scale * LOG2E;
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
         sv.store(vimg(SLOT ^ 1), C::RSTRIDE, tid);
       }
     }
-    __syncthreads();
+    tile_sync<DMA>();
     };
   for (int t = 0; t < ntiles; t += 2) {
     tile_step(std::integral_constant<int, 0>{}, t);
@@ -742,7 +748,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
     }
     store_stats(0);
   }
-  __syncthreads();
+  tile_sync<DMA>();
 
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see attn_fwd_kernel
   const float c = p.scale * LOG2E;
@@ -849,7 +855,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
       }
       store_stats(SLOT ^ 1);
     }
-    __syncthreads();
+    tile_sync<DMA>();
     };
   for (int t = 0; t < ntiles; t += 2) {
     tile_step(std::integral_constant<int, 0>{}, t);
