@@ -648,24 +648,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
   // issue cursor of the stage stream: (itile, ikt) is the next stage to fetch
   int itile = t_beg + jb, ikt = 0;
   if (itile < t_end) set_src(itile);
-  auto issue = [&](int slot) {
+  // The PER requests of a stage are issued in SSTEPS parts, one behind the MFMAs of every k16-step of the stage being computed (part
+  // < 0: all at once).  Issued together right after the barrier, the 48 requests of the eight waves queue up at the CU's one address unit
+  // while no MFMA is left in the pipe (worth 1.5-2 % of the long-K launches).
+  auto issue = [&](int slot, int part) __attribute__((always_inline)) {
     if (itile >= t_end) return;
     char* as = smem + slot * STAGE;
     const int k0 = ikt * BKE;
 #pragma unroll
     for (int j = 0; j < APW; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
+      if (part < 0 || (j * SSTEPS) / PER == part)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < BPW; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + A_BYTES + (wave * BPW + j) * 1024), 16, 0, 0);
-    if (++ikt == nk) {
-      ikt = 0;
-      itile += nbx;
-      if (itile < t_end) set_src(itile);
+      if (part < 0 || ((APW + j) * SSTEPS) / PER == part)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + A_BYTES + (wave * BPW + j) * 1024), 16, 0, 0);
+    if (part < 0 || part == SSTEPS - 1) {
+      if (++ikt == nk) {
+        ikt = 0;
+        itile += nbx;
+        if (itile < t_end) set_src(itile);
+      }
     }
   };
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s);
+  for (int s = 0; s < NS - 1; ++s) issue(s, -1);
   int slot = 0;                                     // ring slot of the stage being computed
   for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
     const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
@@ -689,7 +696,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
       else if (NS == 4 && after == 1) vm_wait_barrier<PER>();
       else vm_wait_barrier<0>();
 #endif
-      issue(slot == 0 ? NS - 1 : slot - 1);
+      const int fill = slot == 0 ? NS - 1 : slot - 1;            // the slot every wave left at this barrier
+#ifdef FK_RING_BURST_ISSUE
+      issue(fill, -1);
+#endif
       const char* as = smem + slot * STAGE;
       const char* bs = as + A_BYTES;
 #ifndef FK_RING_PROBE_NOMMA        // probe builds (tools/): fetch stream only
@@ -710,7 +720,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+#ifndef FK_RING_BURST_ISSUE
+        __builtin_amdgcn_sched_barrier(0);
+        issue(fill, s);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
+#else
+#ifndef FK_RING_BURST_ISSUE
+      issue(fill, -1);
+#endif
 #endif
       slot = slot == NS - 1 ? 0 : slot + 1;
     }
@@ -775,25 +794,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
   // two issue cursors over the same stage stream: A runs two stages ahead of the compute, B one
   int atile = t_beg + jb, akt = 0, btile = atile, bkt = 0;
   if (atile < t_end) { set_a(atile); set_b(btile); }
-  auto issue_a = [&](int slot) {
+  // half = 0 / 1: the first / second two requests of the stage, -1: all four (the steps of the loop issue B in the gaps behind the first
+  // two k16-steps and A behind the last two — the order the counted wait relies on — instead of all eight right after the barrier;
+  // measured -1.5...-2 % on the 256 x 128 kernel, +-0 here)
+  auto issue_a = [&](int slot, int half) __attribute__((always_inline)) {
     if (atile >= t_end) return;
     char* as = aslot(slot);
 #pragma unroll
     for (int j = 0; j < APW; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + akt * 64), (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
-    if (++akt == nk) { akt = 0; atile += nbx; if (atile < t_end) set_a(atile); }
+      if (half < 0 || j / 2 == half)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + akt * 64), (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
+    if (half != 0) { if (++akt == nk) { akt = 0; atile += nbx; if (atile < t_end) set_a(atile); } }
   };
-  auto issue_b = [&](int slot) {
+  auto issue_b = [&](int slot, int half) __attribute__((always_inline)) {
     if (btile >= t_end) return;
     char* bs = bslot(slot);
 #pragma unroll
     for (int j = 0; j < BPW; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + bkt * 64), (lds_void_t*)(bs + (wave * BPW + j) * 1024), 16, 0, 0);
-    if (++bkt == nk) { bkt = 0; btile += nbx; if (btile < t_end) set_b(btile); }
+      if (half < 0 || j / 2 == half)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + bkt * 64), (lds_void_t*)(bs + (wave * BPW + j) * 1024), 16, 0, 0);
+    if (half != 0) { if (++bkt == nk) { bkt = 0; btile += nbx; if (btile < t_end) set_b(btile); } }
   };
-  issue_a(0);
-  issue_b(0);
-  issue_a(1);
+  issue_a(0, -1);
+  issue_b(0, -1);
+  issue_a(1, -1);
   int sa = 0, sb = 0;                               // slots of the stage being computed
   for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
     const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
@@ -807,8 +831,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     for (int kt = 0; kt < nk; ++kt) {
       if (last_tile && kt == nk - 1) vm_wait_barrier<0>(); else vm_wait_barrier<APW>();
-      issue_b(sb ^ 1);
-      issue_a(sa == 0 ? 2 : sa - 1);
+      const int fill_a = sa == 0 ? 2 : sa - 1, fill_b = sb ^ 1;
       const char* as = aslot(sa);
       const char* bs = bslot(sb);
 #ifndef FK_RING_PROBE_NOMMA
@@ -823,7 +846,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < 2) issue_b(fill_b, s); else issue_a(fill_a, s - 2);
+        __builtin_amdgcn_sched_barrier(0);
       }
+#else
+      issue_b(fill_b, -1);
+      issue_a(fill_a, -1);
 #endif
       sa = sa == 2 ? 0 : sa + 1;
       sb ^= 1;

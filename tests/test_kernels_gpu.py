@@ -131,7 +131,9 @@ def test_gemm_tn_large_tile_exact_integers(K, shape):
 
 
 RING_SHAPES = [(4096, 384, 64), (4168, 128, 128), (8200, 1152, 384), (4104, 256, 64), (70000, 256, 128), (66000, 384, 192),
-               (4096, 512, 128), (33000, 768, 64)]
+               (4096, 512, 128), (33000, 768, 64),
+               # long K, N = 384 class: the kernel with split request waves and the 4-slot A ring (one / several tiles per block, ragged rows)
+               (4224, 384, 1536), (8200, 128, 1024), (70000, 384, 1088), (4096, 640, 3072)]
 
 
 @pytest.mark.parametrize("shape", RING_SHAPES)
