@@ -13,7 +13,7 @@ bash tools/profile_step.sh ${P} "round 2 final" > $O/${P}_profile.out 2>&1; tail
 bash tools/pmc_step.sh ${P} > $O/${P}_pmc_step.out 2>&1; tail -3 $O/${P}_pmc_step.out
 bash tools/pmc_attn.sh ${P}_pmc_sq_attention > $O/${P}_pmc_attn.out 2>&1; tail -2 $O/${P}_pmc_attn.out
 FRANKEN_HIP_LIB=$ROOT/frankenstein_amd/variants/lib_stamp.so timeout -k 5 100 python tools/clock_attn.py > $O/${P}_clock_attn.txt 2>&1; tail -2 $O/${P}_clock_attn.txt
-for p in valu_rate mfma_mix mfma_lds mfma_shape mfma16_layout; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/probes/$p.hip -o /tmp/$p && timeout -k 5 100 /tmp/$p > $O/${P}_probe_$p.txt 2>&1; done; tail -2 $O/${P}_probe_mfma_lds.txt
+for p in valu_rate mfma_mix mfma_lds mfma_shape mfma16_layout dma_rowwidth; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/probes/$p.hip -o /tmp/$p && timeout -k 5 100 /tmp/$p > $O/${P}_probe_$p.txt 2>&1; done; tail -2 $O/${P}_probe_mfma_lds.txt
 { echo "== in-tree library"; python tools/gemm_bench.py 5 2>&1 | grep -E "^nt|^tn|sum";
   for v in noepi nomma; do echo "== $v (probe build: $( [ $v = noepi ] && echo 'main loops only, no epilogue' || echo 'fetch stream and epilogue only, no MFMA' ))";
     FRANKEN_HIP_LIB=$ROOT/frankenstein_amd/variants/lib_$v.so python tools/gemm_bench.py 3 2>&1 | grep -E "^nt|sum"; done; } > $O/${P}_gemm_phase_split.txt 2>&1
