@@ -871,6 +871,131 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
   }
 }
 
+// 256 x 192 tile for N = 384 (two column tiles instead of three 128-wide ones).  These launches are bound by the bytes that go through
+// LDS-DMA (57 GB/s per CU out of L2, 24 out of HBM): a 256 x 128 tile moves 384 rows per k-stage for 256 x 128 outputs and the
+// three column tiles fetch the same A rows three times; 256 x 192 moves 448 rows for 256 x 192 outputs and fetches A twice: 22 % fewer
+// bytes for the same product.  Rings as in the 256 x 256 kernel (A: three 32-KiB slots, two stages ahead; B: two 24-KiB slots, one ahead;
+// counted wait vmcnt(4)); every wave owns 32 rows and all 192 columns (6 accumulator tiles), so the epilogue is three 64-column sweeps.
+constexpr int R192_A = 256 * ROW_BYTES, R192_B = 192 * ROW_BYTES, R192_LDS = 3 * R192_A + 2 * R192_B + 8192;
+
+template <typename TO, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring192_kernel(NtArgs p) {
+  using T = bf16_t;
+  constexpr int BM_ = 256, BN_ = 192, APW = 4, BPW = 3, NT6 = 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto aslot = [&](int i) -> char* { return smem + i * R192_A; };
+  auto bslot = [&](int i) -> char* { return smem + 3 * R192_A + i * R192_B; };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int ntn = p.N / BN_;
+  const int ntiles = ((p.M + BM_ - 1) / BM_) * ntn;
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = (nb + 7 - xcd) >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int t_beg = xcd * q8 + min(xcd, r8), t_end = t_beg + q8 + (xcd < r8 ? 1 : 0);
+  const int nk = p.K / 64;
+
+  const T* srcA[APW];
+  const T* srcB[BPW];
+  auto set_a = [&](int tile) {
+    const int m0 = (tile / ntn) * BM_;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const int row = (wave * APW + j) * 8 + (lane >> 3);
+      srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  auto set_b = [&](int tile) {
+    const int n0 = (tile % ntn) * BN_;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      const int row = (wave * BPW + j) * 8 + (lane >> 3);
+      srcB[j] = (const T*)p.B + (int64_t)(n0 + row) * p.ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  int atile = t_beg + jb, akt = 0, btile = atile, bkt = 0;
+  if (atile < t_end) { set_a(atile); set_b(btile); }
+  // part 0 / 1 of a stage's requests (-1: all): B first, A after it - the order the counted wait relies on
+  auto issue_a = [&](int slot, int part) __attribute__((always_inline)) {
+    if (atile >= t_end) return;
+    char* as = aslot(slot);
+#pragma unroll
+    for (int j = 0; j < APW; ++j)
+      if (part < 0 || j / 2 == part)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + akt * 64), (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
+    if (part != 0) { if (++akt == nk) { akt = 0; atile += nbx; if (atile < t_end) set_a(atile); } }
+  };
+  auto issue_b = [&](int slot, int part) __attribute__((always_inline)) {
+    if (btile >= t_end) return;
+    char* bs = bslot(slot);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      if (part < 0 || (j + 1) / 2 == part)                       // part 0: piece 0, part 1: pieces 1 and 2
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + bkt * 64), (lds_void_t*)(bs + (wave * BPW + j) * 1024), 16, 0, 0);
+    if (part != 0) { if (++bkt == nk) { bkt = 0; btile += nbx; if (btile < t_end) set_b(btile); } }
+  };
+  issue_a(0, -1);
+  issue_b(0, -1);
+  issue_a(1, -1);
+  int sa = 0, sb = 0;
+  for (int tile = t_beg + jb; tile < t_end; tile += nbx) {
+    const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN_;
+    const bool last_tile = tile + nbx >= t_end;
+    f32x16 acc[NT6];
+#pragma unroll
+    for (int j = 0; j < NT6; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (last_tile && kt == nk - 1) vm_wait_barrier<0>(); else vm_wait_barrier<APW>();
+      const int fill_a = sa == 0 ? 2 : sa - 1, fill_b = sb ^ 1;
+      const char* as = aslot(sa);
+      const char* bs = bslot(sb);
+#ifndef FK_RING_PROBE_NOMMA
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> fa, fb[NT6];
+        nt_frag<T>(fa, as, wave * 32 + li, s, lh);
+#pragma unroll
+        for (int j = 0; j < NT6; ++j) nt_frag<T>(fb[j], bs, j * 32 + li, s, lh);
+#pragma unroll
+        for (int j = 0; j < NT6; ++j) mma32<T>(acc[j], fb[j], fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < 2) issue_b(fill_b, s); else issue_a(fill_a, s - 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
+      issue_b(fill_b, -1);
+      issue_a(fill_a, -1);
+#endif
+      sa = sa == 2 ? 0 : sa + 1;
+      sb ^= 1;
+    }
+    asm volatile("s_barrier" ::: "memory");          // every wave has read the last stage: its slots (and the spare 8 KiB) are the staging area
+    char* stg = wave < 4 ? aslot(sa == 0 ? 2 : sa - 1) + wave * 8192
+              : (wave < 7 ? bslot(sb ^ 1) + (wave - 4) * 8192 : smem + 3 * R192_A + 2 * R192_B);
+#ifdef FK_RING_PROBE_NOEPI
+    if (acc[0][0] == 123.456f) ((float*)p.C)[tid] = acc[NT6 - 1][3];
+#else
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[2 * c]);
+      if (EPI == 0 && p.res) nt_epilogue<T, TO, true, 1, true, EPI>(p, sub, stg, m0 + wave * 32, n0 + 64 * c, lane, false);
+      else nt_epilogue<T, TO, true, 1, false, EPI>(p, sub, stg, m0 + wave * 32, n0 + 64 * c, lane, false);
+    }
+#endif
+  }
+}
+
+template <typename TO>
+static void launch_ring192(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
+  const int64_t nt = fk_cdiv(M, 256) * (N / 192);
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring192_kernel<TO, 0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, R192_LDS) == hipSuccess);
+  (void)once;
+  hipLaunchKernelGGL((gemm_nt_ring192_kernel<TO, 0>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R192_LDS, s, p);
+}
+
 template <typename TO, int EPI>
 static void launch_ring2_epi(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
   const int64_t nt = fk_cdiv(M, 256) * fk_cdiv(N, 256);
@@ -1339,6 +1464,12 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   if (wide && (N % 256 == 0 || (N % 128 == 0 && N >= 1024))) {   // 256 x 256 tiles, split A/B rings (N = 1152: the last column tile is
                                                                   // half empty, still 4 % faster than 256 x 128 tiles)
     if (out_dtype == FK_BF16) launch_ring2<bf16_t>(p, M, N, s); else launch_ring2<float>(p, M, N, s);
+    FK_CHECK_LAUNCH(name);
+    return FK_OK;
+  }
+  static const bool no_192 = getenv("FK_NT_NO_192") != nullptr;        // tuning knob: 256 x 128 tiles for N = 384 / 768 too
+  if (wide && N % 192 == 0 && N % 256 != 0 && N <= 768 && mode == 0 && !rope.table && !no_192) {   // N = 384: two 192-column tiles
+    if (out_dtype == FK_BF16) launch_ring192<bf16_t>(p, M, N, s); else launch_ring192<float>(p, M, N, s);
     FK_CHECK_LAUNCH(name);
     return FK_OK;
   }
