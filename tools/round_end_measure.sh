@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything the round's profiles/ are made from, in one GPU-box call (run from the repo root): full GPU suite, the benchmark line, the
 # per-kernel trace of the step, the counter passes, the attention SQ counters, the clock probe, the issue probes and the GEMM phase split.
-# Each step writes under gpurun_out/; a failing step stops the rest (set -e).  usage: tools/round_end_measure.sh PREFIX (e.g. r02_e)
+# Each step writes under gpurun_out/; a failing step stops the rest (set -e).  usage: tools/round_end_measure.sh PREFIX (e.g. r02_f)
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-P=${1:-r02_e}
+P=${1:-r02_f}
 O=$ROOT/gpurun_out
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/${P}_gpu_tests.log 2>&1; tail -2 $O/${P}_gpu_tests.log
