@@ -1204,22 +1204,27 @@ FK_DEV unsigned lds_addr(const char* p) {
   return (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) const char*)p);
 }
 
+// TB = columns of B per tile: 128 (256-byte image rows) or 192 (two column tiles instead of three for N2 = 384: the launch is bound by the
+// bytes that go through LDS-DMA; image rows keep a 512-byte pitch so that the 64-byte-chunk swizzle stays inside a 256-byte
+// block, the last 128 bytes of a row are padding that the requests fill with column 0).
+template <int TB>
 __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
+  constexpr int B_ROW = TB == 128 ? 256 : 512, B_BYTES = TG_K * B_ROW, STAGE = TG_A_BYTES + B_BYTES, NJ = TB / 64, WB = TB / 2;
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int nt2 = p.N2 / TG_B, ntiles = (p.N1 / TG_A) * nt2;
+  const int nt2 = p.N2 / TB, ntiles = (p.N1 / TG_A) * nt2;
   const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
   const int split = (int)(L / ntiles), tile = (int)(L % ntiles);
-  const int a0 = (tile / nt2) * TG_A, b0 = (tile % nt2) * TG_B;
+  const int a0 = (tile / nt2) * TG_A, b0 = (tile % nt2) * TB;
   const int mbeg = split * p.rows_per_split;
   const int mend = min(p.M, mbeg + p.rows_per_split);
   const int nk = (mend - mbeg) / TG_K;
 
   // per-lane DMA sources: piece q of an image = LDS bytes [1024 q, 1024 q + 1024), lane l -> 16 B at 1024 q + 16 l
-  constexpr int APW = TG_A_BYTES / 8192, BPW = TG_B_BYTES / 8192, PER = APW + BPW;     // 3 + 1 LDS-DMA instructions per wave and stage
+  constexpr int APW = TG_A_BYTES / 8192, BPW = B_BYTES / 8192, PER = APW + BPW;     // 3 + 1 (or 2) LDS-DMA instructions per wave and stage
   const T* srcA[APW];
   const T* srcB[BPW];
 #pragma unroll
@@ -1230,13 +1235,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
-    const int o = (wave * BPW + j) * 1024 + lane * 16, row = o / TG_B_ROW, bc = o % TG_B_ROW;
-    const int sc = ((((bc >> 6) ^ row) & 3) << 6) + (bc & 63);
+    const int o = (wave * BPW + j) * 1024 + lane * 16, row = o / B_ROW, bc = o % B_ROW;
+    int sc = (bc & ~255) + ((((bc >> 6) ^ row) & 3) << 6) + (bc & 63);
+    if (sc >= TB * 2) sc = 0;                                   // padding of the 512-byte pitch: any valid column
     srcB[j] = (const T*)p.B + (int64_t)(mbeg + row) * p.ldb + b0 + sc / 2;
   }
   const int64_t astep = (int64_t)TG_K * p.lda, bstep = (int64_t)TG_K * p.ldb;
   auto stage = [&](int buf) {
-    char* as = smem + buf * TG_STAGE;
+    char* as = smem + buf * STAGE;
 #pragma unroll
     for (int j = 0; j < APW; ++j) {
       __builtin_amdgcn_global_load_lds((glb_void_t*)srcA[j], (lds_void_t*)(as + (wave * APW + j) * 1024), 16, 0, 0);
@@ -1250,20 +1256,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
   };
 
   // fragment read bases (stage 0): lane (g = lane>>4, i = lane&15) reads row 8*(g>>1) + (i>>2) (+16 s + 4 t by immediate offset)
-  unsigned fbase[5];
+  unsigned fbase[3 + NJ];
   {
     const int g = lane >> 4, i = lane & 15, row = 8 * (g >> 1) + (i >> 2), dc = 16 * (g & 1) + 4 * (i & 3);
 #pragma unroll
     for (int q = 0; q < 3; ++q) fbase[q] = lds_addr(smem) + tg_off<TG_A_ROW>(row, (wm * 96 + q * 32 + dc) * 2);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) fbase[3 + q] = lds_addr(smem) + TG_A_BYTES + tg_off<TG_B_ROW>(row, (wn * 64 + q * 32 + dc) * 2);
+    for (int q = 0; q < NJ; ++q) fbase[3 + q] = lds_addr(smem) + TG_A_BYTES + tg_off<B_ROW>(row, (wn * WB + q * 32 + dc) * 2);
   }
 
-  f32x16 acc[3][2];
+  f32x16 acc[3][NJ];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -1282,32 +1288,35 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
     else if (after == 1) vm_wait_barrier<PER>();
     else vm_wait_barrier<0>();
     if (kt + TG_NS - 1 < nk) stage(slot == 0 ? TG_NS - 1 : slot - 1);
-    const unsigned bo = slot * TG_STAGE;
+    const unsigned bo = slot * STAGE;
     slot = slot == TG_NS - 1 ? 0 : slot + 1;
-    Frag<T> f0[5], f1[5];
-#define TG_LOAD(F, S)                                                      \
-    tg_frag<TG_A_ROW, S>(F[0], fbase[0] + bo); tg_frag<TG_A_ROW, S>(F[1], fbase[1] + bo); \
-    tg_frag<TG_A_ROW, S>(F[2], fbase[2] + bo); tg_frag<TG_B_ROW, S>(F[3], fbase[3] + bo); \
-    tg_frag<TG_B_ROW, S>(F[4], fbase[4] + bo);
-#define TG_MMA(F)                                                          \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i)                          \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], F[i], F[3 + j]);
-    TG_LOAD(f0, 0)
-    TG_LOAD(f1, 1)
-    lgkm_wait<10>();
-    TG_MMA(f0)
+    Frag<T> f0[3 + NJ], f1[3 + NJ];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) tg_frag<TG_A_ROW, 0>(f0[q], fbase[q] + bo);
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) tg_frag<B_ROW, 0>(f0[3 + q], fbase[3 + q] + bo);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) tg_frag<TG_A_ROW, 1>(f1[q], fbase[q] + bo);
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) tg_frag<B_ROW, 1>(f1[3 + q], fbase[3 + q] + bo);
+    lgkm_wait<2 * (3 + NJ)>();                       // the first k16-step's fragments (LDS reads return in order)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) mma32<T>(acc[i][j], f0[i], f0[3 + j]);
     lgkm_wait<0>();
-    TG_MMA(f1)
-#undef TG_LOAD
-#undef TG_MMA
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) mma32<T>(acc[i][j], f1[i], f1[3 + j]);
   }
 
   float* out = (p.nsplit > 1) ? p.ws + (int64_t)split * p.N1 * p.N2 : p.C;
   const int64_t ldo = (p.nsplit > 1) ? p.N2 : p.ldc;
   const bool accum = (p.nsplit == 1) && p.accumulate;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = b0 + wn * 64 + j * 32 + li;
+  for (int j = 0; j < NJ; ++j) {
+    const int n = b0 + wn * WB + j * 32 + li;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1408,10 +1417,18 @@ int tn_splits(int64_t M, int64_t N1, int64_t N2, int bkm) {
 }
 // large-tile TN path: bf16, M % 64 == 0, N1 % 384 == 0, N2 % 128 == 0 and enough rows to be worth one block per CU
 bool tn_big_ok(int64_t M, int64_t N1, int64_t N2, int dtype) {
-  return dtype == FK_BF16 && M % TG_K == 0 && M >= 16384 && N1 % TG_A == 0 && N2 % TG_B == 0;
+  return dtype == FK_BF16 && M % TG_K == 0 && M >= 16384 && N1 % TG_A == 0 && (N2 % TG_B == 0 || N2 % 192 == 0);
+}
+// B columns per tile: 192 where it divides N2 and A is wide (fewer bytes through LDS-DMA: A is fetched N2 / TB times).  Measured on the
+// cfg2 shapes: 3072 x 384 -7 %, 1152 x 384 and 384 x 1536 +-1 %, 384 x 384 +10 % (more split slabs, 25 % padding in the B requests) -> only
+// for N1 >= 2048.
+int tn_big_tb(int64_t N1, int64_t N2) {
+  static const bool no192 = getenv("FK_TN_NO_192") != nullptr;
+  if (N2 % TG_B != 0) return 192;
+  return (N2 % 192 == 0 && N1 >= 2048 && !no192) ? 192 : TG_B;
 }
 int tn_big_splits(int64_t M, int64_t N1, int64_t N2) {
-  const int64_t tiles = (N1 / TG_A) * (N2 / TG_B);
+  const int64_t tiles = (N1 / TG_A) * (N2 / tn_big_tb(N1, N2));
   int64_t want = 256 / tiles;                               // one wave of blocks, one block per CU
   const int64_t maxs = M / 512;                             // >= 512 rows (16 k-stages) per split
   if (want > maxs) want = maxs;
@@ -1554,10 +1571,18 @@ int fk_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
   dim3 grid((unsigned)(fk_cdiv(N1, BM) * fk_cdiv(N2, BN) * ns)), block(NTHREADS);
   hipStream_t s = (hipStream_t)stream;
   if (big) {
-    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TG_NS * TG_STAGE) == hipSuccess);
-    (void)once;
-    dim3 bgrid((unsigned)((N1 / TG_A) * (N2 / TG_B) * ns));
-    hipLaunchKernelGGL(gemm_tn_big_kernel, bgrid, dim3(512), TG_NS * TG_STAGE, s, p);
+    const int tb = tn_big_tb(N1, N2);
+    dim3 bgrid((unsigned)((N1 / TG_A) * (N2 / tb) * ns));
+    if (tb == 192) {
+      constexpr int LDS192 = TG_NS * (TG_A_BYTES + TG_K * 512);
+      static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS192) == hipSuccess);
+      (void)once;
+      hipLaunchKernelGGL(gemm_tn_big_kernel<192>, bgrid, dim3(512), LDS192, s, p);
+    } else {
+      static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, TG_NS * TG_STAGE) == hipSuccess);
+      (void)once;
+      hipLaunchKernelGGL(gemm_tn_big_kernel<128>, bgrid, dim3(512), TG_NS * TG_STAGE, s, p);
+    }
   } else if (dtype == FK_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 4 * TILE_BYTES, s, p);
   else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 4 * TILE_BYTES, s, p);
   FK_CHECK_LAUNCH("fk_gemm_tn");

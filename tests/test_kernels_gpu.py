@@ -108,7 +108,9 @@ def test_gemm_tn(K, dtype, shape):
     close(acc, ref + 1, torch.float32, atol32=2e-3 if dtype == torch.float32 else 5e-2 * math.sqrt(M / 1000), rtol32=1e-4 if dtype == torch.float32 else 2e-2)
 
 
-@pytest.mark.parametrize("shape", [(16384 + 192, 384, 256), (24576, 768, 128), (16384, 384, 384), (16384 + 32, 384, 128), (16384 + 96, 768, 256)])
+@pytest.mark.parametrize("shape", [(16384 + 192, 384, 256), (24576, 768, 128), (16384, 384, 384), (16384 + 32, 384, 128), (16384 + 96, 768, 256),
+                                   # the 384 x 192 tile (512-byte-pitch B image with padding): taken for N2 % 192 == 0 with N1 >= 2048, or when 128 does not divide N2
+                                   (16384 + 64, 2304, 384), (32768, 384, 1536), (16384 + 32, 768, 192)])
 def test_gemm_tn_large_tile_exact_integers(K, shape):
     """the 384x128-tile LDS-DMA weight-gradient kernel (bf16, M % 32 == 0, N1 % 384 == 0, N2 % 128 == 0; 32-row stages in a 4-slot
     ring, so splits with an odd and an even number of stages and fewer stages than slots in the tail are all here): asymmetric integer
