@@ -282,3 +282,47 @@ def test_generated_streams_are_current(tmp_path, gen):
     env = {k: v for k, v in os.environ.items() if not k.startswith("FK_GEN_")}
     subprocess.run([sys.executable, str(root / "tools" / "gen" / f"gen_{gen}_asm.py"), str(out)], check=True, env=env, capture_output=True)
     assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / f"attn_{gen}_asm.inc").read_bytes()
+
+
+def _verify_stream():
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("verify_stream", Path(__file__).resolve().parents[1] / "tools" / "gen" / "verify_stream.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd", "dq16"])
+def test_generated_streams_keep_their_hazard_rules(gen):
+    """every asm block of the committed streams replayed against the rules the generators promise (counted LDS waits, VALU -> consumer
+    distance, MFMA result -> VALU distance, fragment overwrite behind its MFMA, M0 -> LDS-DMA distance): tools/gen/verify_stream.py"""
+    from pathlib import Path
+    vs = _verify_stream()
+    text = (Path(__file__).resolve().parents[1] / "frankenstein_amd" / "csrc" / f"attn_{gen}_asm.inc").read_text()
+    blocks = list(vs.blocks(text))
+    assert len(blocks) >= 3
+    errs = [e for name, ins in blocks for e in vs.check_block(name, ins)]
+    assert not errs, errs[:5]
+
+
+def test_stream_verifier_sees_violations():
+    """the checker itself: each rule broken once in a small hand-written block"""
+    vs = _verify_stream()
+    ok = ["ds_read_b128 v[100:103], %[a] offset:0", "s_waitcnt lgkmcnt(0)",
+          "v_mfma_f32_32x32x16_bf16 v[104:119], v[100:103], %[k], 0", "v_mfma_f32_32x32x16_bf16 v[120:135], v[100:103], %[k], 0",
+          "v_mfma_f32_32x32x16_bf16 v[136:151], v[100:103], %[k], 0", "v_exp_f32_e32 v104, v104", "s_nop 0", "v_mul_f32_e32 v105, v104, v104",
+          "s_add_u32 m0, %[l], 0", "s_nop 0", "global_load_lds_dwordx4 %[vo], %[kb]"]
+    assert vs.check_block("ok", ok) == []
+    no_wait = [ok[0]] + ok[2:]
+    assert any("may still be outstanding" in e for e in vs.check_block("b", no_wait))
+    early_valu = ok[:3] + ["v_exp_f32_e32 v104, v104"]
+    assert any("further MFMA" in e for e in vs.check_block("b", early_valu))
+    back_to_back = ok[:6] + ["v_mul_f32_e32 v105, v104, v104"]
+    assert any("right in front" in e for e in vs.check_block("b", back_to_back))
+    overwrite = ok[:3] + ["ds_read_b128 v[100:103], %[a] offset:64", "s_waitcnt lgkmcnt(0)"]
+    assert any("operand of the MFMA issued last" in e for e in vs.check_block("b", overwrite))
+    m0_late = ok[:8] + ["s_add_u32 m0, %[l], 0", "global_load_lds_dwordx4 %[vo], %[kb]"]
+    assert any("M0 written" in e for e in vs.check_block("b", m0_late))
+    unwaited = ok + ["ds_read_b128 v[100:103], %[a] offset:0"]
+    assert any("not waited for" in e for e in vs.check_block("b", unwaited))
