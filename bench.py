@@ -108,14 +108,44 @@ def mfma_util_pmc():
         return None
 
 
+def visible_gpus():
+    """GPU count WITHOUT loading the HIP runtime (torch.cuda.device_count() may fall back to hipGetDeviceCount = hipInit in this
+    process): FK_VISIBLE_GPUS if set, else the KFD topology nodes that have SIMDs; None when neither can be read (the ranks then
+    report a missing device themselves)."""
+    if os.environ.get("FK_VISIBLE_GPUS"):
+        return int(os.environ["FK_VISIBLE_GPUS"])
+    nodes = Path("/sys/class/kfd/kfd/topology/nodes")
+    if not nodes.is_dir():
+        return 0                                         # no KFD driver: no AMD GPU on this host
+    try:
+        n = 0
+        for node in nodes.iterdir():
+            props = dict(l.split() for l in (node / "properties").read_text().splitlines() if len(l.split()) == 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except Exception:
+        return None
+
+
+def dp_env(env=None):
+    """Environment of a data-parallel rank.  NCCL_MAX_NCHANNELS bounds the workgroups (= CUs) an RCCL collective occupies: the
+    all-reduces of GradSync run on the communication stream BESIDE persistent one-block-per-CU GEMM grids, and a second occupant that
+    takes CUs at random makes those grids run a second partial wave (DESIGN.md 5.1 "two large-tile grids on two streams": 65 ms steps
+    became 80-160 ms).  81 MB of gradients per 50 ms step need ~3 GB/s per link, so a few channels are plenty."""
+    env = os.environ if env is None else env
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_MAX_NCHANNELS", "8")
+    return env
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: run `torch.distributed.run` as a child process (fresh ranks; this process
-    has not initialised the GPU and never does) and relay its output."""
+    never loads the HIP runtime) and relay its output."""
     import socket
     import subprocess
     if not args.dry_run:
-        n = torch.cuda.device_count()               # counting devices does not initialise HIP
-        if n < args.gpus:
+        n = visible_gpus()
+        if n is not None and n < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) visible on this host; "
                   f"run with --gpus <= {n}, or launch one rank per GPU on a node that has {args.gpus}", file=sys.stderr)
             return 2
@@ -124,8 +154,7 @@ def self_launch(args) -> int:
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    proc = subprocess.run(cmd, env=env)
+    proc = subprocess.run(cmd, env=dp_env(dict(os.environ)))
     return proc.returncode
 
 
@@ -138,11 +167,46 @@ def dry_run(args, rank, world):
     t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the data-parallel self-checks of the real run, on a toy arena: bucketed exchange, replica checksum, exposed-wait bookkeeping
+    from frankenstein_amd.utils import train_utils as tu
+    torch.manual_seed(rank)                              # replicas start DIFFERENT: the arena broadcast has to align them
+    net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 3))
+    arena = tu.ParamArena(net)
+    gs = tu.GradSync(arena, bucket_bytes=4096, measure=True)
+    x = torch.randn(8, 37, generator=torch.Generator().manual_seed(100 + rank))
+    for _ in range(max(1, args.steps)):
+        net(x).pow(2).mean().backward()
+        scale = gs.finish()
+        with torch.no_grad():
+            arena.flat.add_(arena.grad, alpha=-0.1 * scale)
+            arena.grad.zero_()
+    dp = dp_report(gs, arena, torch.device("cpu"), args.steps)
     if rank == 0:
         print(json.dumps({"metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "dry_run": True, "n_gpus": world,
-                          "world": world, "steps": args.steps, "warmup": args.warmup, "max_rank_time_s": float(t)}), flush=True)
+                          "world": world, "steps": args.steps, "warmup": args.warmup, "max_rank_time_s": float(t), "dp": dp,
+                          "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS")}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def dp_report(gs, arena, dev, steps):
+    """Self-validation of a data-parallel run, identical on every rank after the collectives inside:
+    param_checksum_equal — MIN and MAX over ranks of a checksum of the parameter arena agree (replicas did not drift apart);
+    exposed_comm_ms — per step, time the compute stream spent waiting for the gradient exchange after the last backward kernel
+    (HIP events around GradSync.finish; mean over the timed steps, MAX over ranks);  n_buckets / bucket_mb — the exchange's shape."""
+    import torch.distributed as dist
+    flat = arena.flat.detach()
+    cs = torch.stack([flat.double().sum(), flat.double().abs().sum(), (flat.double() * torch.arange(1, flat.numel() + 1, device=flat.device,
+                                                                     dtype=torch.float64).remainder(8191)).sum()]).to(dev)
+    lo, hi = cs.clone(), cs.clone()
+    exp = torch.tensor([gs.exposed_ms_mean(last=steps)], dtype=torch.float64, device=dev)
+    if gs.active:
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(exp, op=dist.ReduceOp.MAX)
+    return {"param_checksum_equal": bool(torch.equal(lo, hi)), "param_checksum": [float(v) for v in cs.cpu()],
+            "exposed_comm_ms": round(float(exp), 4), "n_buckets": len(gs.buckets),
+            "bucket_mb": [round((e - s0) * 4 / 2 ** 20, 2) for s0, e, _ in gs.buckets], "world": gs.world}
 
 
 def parity_block():
@@ -184,6 +248,7 @@ def main():
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
+        dp_env()                                 # also when an external launcher (the driver's torchrun) started the ranks
         dist.init_process_group("nccl", device_id=dev)
 
     from frankenstein_amd import kernels as K
@@ -194,6 +259,7 @@ def main():
     tcfg = tu.TrainConfig(batch_size=args.batch * world, mixed_precision=(args.dtype == "bf16"), use_scheduler=False,
                           learning_rate=1e-4)
     opt = tu.FusedAdamW(model, lr=tcfg.learning_rate, weight_decay=tcfg.weight_decay, grad_clip=tcfg.grad_clip)
+    opt.sync.measure = world > 1
     sched = tu.init_lr_scheduler(tcfg)
 
     B, T, Cn = args.batch, 600, 256
@@ -226,6 +292,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     assert torch.isfinite(loss).item(), "loss diverged"
+    dp = dp_report(opt.sync, opt.arena, dev, args.steps) if world > 1 else None
 
     if rank == 0:
         frames = B * T * world * args.steps
@@ -269,6 +336,7 @@ def main():
                               "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                               "frac": round(value / world * FLOP_PER_FRAME / MFMA_PEAK_BF16, 4),
                               "note": "whole step per GPU: frames/s x 1.8173 GFLOP/frame (SURVEY §8d)"},
+            "dp": dp, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS") if world > 1 else None,
             "kernel_families": detail,
             "loss": round(float(loss), 5),
             "parity": parity_block(),

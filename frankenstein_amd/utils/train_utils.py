@@ -139,9 +139,12 @@ class GradSync:
     1/world is folded into the optimizer kernel) as soon as every parameter of the bucket has its gradient,
     asynchronously on the process group's communication stream, so the exchange overlaps the remaining backward."""
 
-    def __init__(self, arena: ParamArena, group=None, bucket_bytes: int = 8 << 20, always: bool = False):
+    def __init__(self, arena: ParamArena, group=None, bucket_bytes: int = 8 << 20, always: bool = False, measure: bool = False):
         import torch.distributed as dist
         self.dist, self.group, self.arena = dist, group, arena
+        # measure=True: bracket the wait for the buckets in finish() with timestamps on the compute stream (HIP events; wall clock for
+        # CPU tensors) -> exposed_ms_mean(): how long the step sat waiting for the exchange after its last backward kernel
+        self.measure, self._exposed = measure, []
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.enabled = True
         # always=True: issue the collectives also in a one-rank group (identity) — how the RCCL path is rehearsed on a one-GPU box
@@ -168,6 +171,23 @@ class GradSync:
             for i, p in enumerate(arena.params):
                 hook = self._make_hook(self.bucket_of[i])
                 p.register_post_accumulate_grad_hook(hook)     # also fires when engine.wgrad wrote the gradient itself
+
+    def _mark(self):
+        if self.arena.grad.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+        return time.perf_counter()
+
+    def exposed_ms_mean(self, last: Optional[int] = None) -> float:
+        """mean over the last `last` measured steps (all by default) of the compute stream's wait for the exchange, in ms; call after
+        a device synchronisation"""
+        pairs = self._exposed[-last:] if last else self._exposed
+        if not pairs:
+            return 0.0
+        ms = [a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3 for a, b in pairs]
+        return sum(ms) / len(ms)
 
     def broadcast_parameters(self, src: int = 0):
         """Every rank takes the master parameters of group rank `src` (one collective over the flat arena)."""
@@ -207,12 +227,17 @@ class GradSync:
                 if not self._launched[b]:
                     self._launch(b)
             side = E.wgrad_stream()
+            t0 = self._mark() if self.measure else None
             for w in self._works:
                 if side is not None:
                     with torch.cuda.stream(side):
                         w.wait()
                 else:
                     w.wait()
+            if self.measure:
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side)
+                self._exposed.append((t0, self._mark()))
         self._works.clear()
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
@@ -241,15 +266,58 @@ class FusedAdamW:
         self.param_groups = [dict(params=self.arena.params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)]
         self.grad_clip = grad_clip
         self.t = 0
+        # torch.optim.AdamW leaves a parameter alone whose .grad is None (after the reference's zero_grad(set_to_none=True),
+        # utils/train_utils.py:134, that is a parameter the backward never reached): no decay, no moment update, its own step count.
+        # The arena's gradients are never None, so "was reached" is recorded by a post-accumulate-grad hook per parameter (it also
+        # fires when engine.wgrad / engine.norm_bwd wrote the gradient into the arena themselves).
+        self._touched = [False] * len(self.arena.params)
+        self._lag: Optional[List[int]] = None       # per parameter: optimizer steps it sat out (None: no parameter ever did)
+        for i, p in enumerate(self.arena.params):
+            p.register_post_accumulate_grad_hook(self._make_touch_hook(i))
         self.sync = GradSync(self.arena, group, bucket_bytes, always=sync_always)
+
+    def _make_touch_hook(self, i: int):
+        def hook(_param):
+            self._touched[i] = True
+        return hook
+
+    def mark_touched(self, flags=None) -> None:
+        """Declare which parameters received a gradient since the last step() when the gradients were not produced by an eager
+        backward (a replayed hipGraph, a hand-written arena.grad): `flags` is a sequence of booleans, None = all of them."""
+        n = len(self.arena.params)
+        self._touched = [True] * n if flags is None else [bool(f) for f in flags]
+        assert len(self._touched) == n
 
     def zero_grad(self, set_to_none: bool = True):
         self.arena.grad.zero_()
         self.arena.rebind_grads()
+        self._touched = [False] * len(self.arena.params)
+
+    def _update_ranges(self):
+        """[(start, end, t)] element ranges of the arena to update with bias-correction step t: one range in the usual case (every
+        parameter reached by the backward, none ever skipped); otherwise maximal runs of adjacent reached parameters with equal
+        step counts.  Parameters the backward did not reach are left out (torch.optim.AdamW: `if p.grad is None: continue`)."""
+        a = self.arena
+        if all(self._touched) and self._lag is None:
+            return [(0, a.numel, self.t)]
+        if self._lag is None:
+            self._lag = [0] * len(a.params)
+        out = []
+        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+            if not self._touched[i]:
+                self._lag[i] += 1
+                continue
+            e, t = o + (p.numel() + 3) // 4 * 4, self.t - self._lag[i]
+            if out and out[-1][1] == o and out[-1][2] == t:
+                out[-1] = (out[-1][0], e, t)
+            else:
+                out.append((o, e, t))
+        return out
 
     def step(self):
-        """Updates EVERY arena parameter (weight decay and moment decay included), also one that received no gradient this
-        step — torch.optim.AdamW skips those; every model in this repository uses all its parameters every step."""
+        """clip + AdamW + zero_grad over the arena: ONE launch when every parameter received a gradient since the last step (every
+        model of the reference, every step); a parameter that did not is skipped like torch.optim.AdamW skips `grad is None` — no
+        weight decay, no moment decay, its bias-correction count does not advance (utils/train_utils.py:117-119,134,143)."""
         g = self.param_groups[0]
         a = self.arena
         p0, p1 = a.params[0], a.params[-1]
@@ -262,18 +330,22 @@ class FusedAdamW:
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)      # join the weight-gradient stream before the update
         self.t += 1
-        K.adamw_step_(self.arena.flat, self.arena.grad, self.m, self.v, self.t, g['lr'], g['betas'][0], g['betas'][1],
-                      g['eps'], g['weight_decay'], clip=self.grad_clip or 0.0, grad_scale=scale, zero_grad=True)
+        for s0, s1, t in self._update_ranges():
+            K.adamw_step_(a.flat[s0:s1], a.grad[s0:s1], self.m[s0:s1], self.v[s0:s1], t, g['lr'], g['betas'][0], g['betas'][1],
+                          g['eps'], g['weight_decay'], clip=self.grad_clip or 0.0, grad_scale=scale, zero_grad=True)
+        self._touched = [False] * len(a.params)
         E.bump_weight_epoch()
         E.refresh_shadows(self.arena.params)       # every weight shadow re-packed from the new masters in one launch
 
     def state_dict(self):
-        return dict(t=self.t, m=self.m, v=self.v, param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+        return dict(t=self.t, m=self.m, v=self.v, lag=None if self._lag is None else list(self._lag),
+                    param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
 
     def load_state_dict(self, sd):
         """Resume: step count, both moment arenas and the hyper-parameters (the parameters themselves travel with the model)."""
         assert sd["m"].numel() == self.m.numel() and sd["v"].numel() == self.v.numel(), "optimizer state of another model"
         self.t = int(sd["t"])
+        self._lag = None if sd.get("lag") is None else [int(x) for x in sd["lag"]]
         self.m.copy_(sd["m"].to(self.m.device))
         self.v.copy_(sd["v"].to(self.v.device))
         for g, src in zip(self.param_groups, sd.get("param_groups", [])):
@@ -293,19 +365,59 @@ def enable_fused_head_loss(model: torch.nn.Module, on: bool = True) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ the step
+# What grad_accum > 1 means.  The reference wraps the step in `with accelerator.accumulate(model)` but zeroes the gradients BEFORE the
+# forward (utils/train_utils.py:133-134), and accelerate's optimizer wrapper executes zero_grad() and step() only on "sync" micro-steps.
+# So on a sync micro-step the gradients of the earlier micro-batches are wiped before the forward, and the update uses the gradient of
+# THAT micro-batch alone, scaled by 1 / grad_accum (accelerator.backward divides the loss); the other micro-batches only contribute their
+# logged loss.  tests/golden/train_accum.npz pins this against the reference's own loop running under accelerate.
+#   "reference": reproduce exactly that (default: a drop-in gives the reference's numbers).  The backward of a non-sync micro-step
+#                cannot influence anything, so only its forward runs (the loss is logged, :147).
+#   "sum":       what the construct is meant to do: gradients of all grad_accum micro-batches summed (each loss / grad_accum), one
+#                update — equal to one step on the concatenated batch for a mean-reduced loss.
+ACCUMULATE = "reference"
+
+
+class GradAccumulation:
+    """accelerate's GradientState as the reference drives it (Accelerator(gradient_accumulation_steps=k), utils/train_utils.py:98,133):
+    a micro-step is a sync step when it is the k-th since the last reset, or the last batch of the loader — which also resets the
+    count (accelerate's sync_with_dataloader default)."""
+
+    def __init__(self, grad_accum: int):
+        self.k, self.count = max(1, int(grad_accum)), 0
+
+    def sync(self, end_of_loader: bool = False) -> bool:
+        if end_of_loader:
+            self.count = 0
+            return True
+        self.count += 1
+        return self.count % self.k == 0
+
+
 def train_step(model, batch, optimizer: FusedAdamW, step: int, cfg: TrainConfig, scheduler=None,
-               micro_step: int = 0):
-    """One iteration of the reference's hot loop (utils/train_utils.py:128-148).  With cfg.grad_accum > 1 call it
-    once per micro-batch (micro_step = 0..grad_accum-1): gradients accumulate, the exchange + update run on the last."""
+               micro_step: int = 0, sync: Optional[bool] = None, accumulate: Optional[str] = None):
+    """One iteration of the reference's hot loop (utils/train_utils.py:128-148): lr = get_lr(step) -> zero_grad -> forward ->
+    backward (-> DP gradient mean) -> clip_grad_value_ -> AdamW.step().  With cfg.grad_accum > 1 call it once per micro-batch;
+    `sync` says whether this micro-step ends an accumulation window (default: micro_step == grad_accum - 1; run_train_model passes
+    accelerate's rule incl. the end of the loader), `accumulate` picks the semantics (module default ACCUMULATE, see above).
+    Returns the un-scaled loss of this micro-batch (what the reference logs)."""
     get_lr = scheduler or init_lr_scheduler(cfg)
     lr = get_lr(step)
     for g in optimizer.param_groups:
         g['lr'] = lr
     inputs, labels, date_info = batch
-    last = micro_step == cfg.grad_accum - 1
+    k = max(1, cfg.grad_accum)
+    mode = accumulate or ACCUMULATE
+    assert mode in ("reference", "sum"), mode
+    last = (micro_step == k - 1) if sync is None else bool(sync)
     optimizer.sync.enabled = last
+    if k > 1 and mode == "reference":
+        if not last:
+            with torch.no_grad():
+                loss, _ = model(inputs, labels, date_info=date_info)
+            return loss.detach()
+        optimizer.zero_grad()             # :134 on a sync micro-step: whatever was accumulated is dropped
     loss, _ = model(inputs, labels, date_info=date_info)
-    (loss / cfg.grad_accum if cfg.grad_accum > 1 else loss).backward()
+    (loss / k if k > 1 else loss).backward()
     if last:
         optimizer.step()
     return loss.detach()
@@ -339,6 +451,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._fwd_bwd()
+        self._touched = list(optimizer._touched)       # which parameters the captured backward reaches (hooks do not run on replay)
         optimizer.zero_grad()                          # capture recorded the launches, it did not run them
 
     def _fwd_bwd(self):
@@ -360,6 +473,7 @@ class GraphedTrainStep:
         for g in self.optimizer.param_groups:
             g['lr'] = lr
         self.graph.replay()
+        self.optimizer.mark_touched(self._touched)
         self.optimizer.step()
         return self.loss
 
@@ -407,13 +521,15 @@ def run_train_model(model, datasets, config, project_name='transformer', save_fo
     optimizer = FusedAdamW(model, lr=config.learning_rate, weight_decay=config.weight_decay, grad_clip=config.grad_clip)
     scheduler = init_lr_scheduler(config)
     to_dev = lambda b: tuple(t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in b)
-    overall_step, best_val, micro = 0, float('inf'), 0
+    overall_step, best_val = 0, float('inf')
+    accum = GradAccumulation(config.grad_accum)
     done = False
     while not done:
-        for batch in train_loader:
+        n_batches = len(train_loader)
+        for i_batch, batch in enumerate(train_loader):
             batch = shard_batch(to_dev(batch), rank, world)
-            loss = train_step(model, batch, optimizer, overall_step, config, scheduler, micro)
-            micro = (micro + 1) % config.grad_accum
+            loss = train_step(model, batch, optimizer, overall_step, config, scheduler,
+                              sync=accum.sync(end_of_loader=i_batch == n_batches - 1))
             overall_step += 1
             if rank == 0:
                 print('*', end='')

@@ -65,3 +65,39 @@ def train_step(loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor], sd: D
         np_, st["m"], st["v"] = adamw_step(p.detach(), gc, st["m"], st["v"], step, lr, weight_decay)
         new_sd[k] = np_
     return loss.detach(), gout, new_sd
+
+
+def accum_sync_flags(n_micro: int, grad_accum: int, batches_per_epoch: int):
+    """Which of the first n_micro micro-steps of the reference loop are "sync" steps under accelerate (utils/train_utils.py:98,133:
+    Accelerator(gradient_accumulation_steps=k) + `with accelerator.accumulate(model)`): the k-th micro-step since the last reset, or
+    the last batch of the loader, which also resets the count (GradientState.sync_with_dataloader)."""
+    flags, count = [], 0
+    for i in range(n_micro):
+        if i % batches_per_epoch == batches_per_epoch - 1:
+            count = 0
+            flags.append(True)
+        else:
+            count += 1
+            flags.append(count % grad_accum == 0)
+    return flags
+
+
+def train_loop_accum(loss_fn, sd: Dict[str, torch.Tensor], batches, grad_accum: int, batches_per_epoch: int, lr_fn,
+                     weight_decay: float = 1e-5, grad_clip: float = 1.0):
+    """The reference's hot loop with grad_accum > 1, restated (utils/train_utils.py:127-148 as it executes under accelerate):
+    zero_grad() (:134) and optimizer.step() (:143) are no-ops except on sync micro-steps, and zero_grad comes BEFORE the forward, so
+    a sync micro-step updates with the gradient of its own micro-batch alone, divided by grad_accum (accelerator.backward, :139);
+    lr = scheduler(overall_step) of that micro-step (:129).  `loss_fn(sd, batch)` -> scalar loss.
+    Returns (per-micro-step losses, per-micro-step sync flags, final sd)."""
+    state: Dict[str, Dict[str, torch.Tensor]] = {}
+    flags = accum_sync_flags(len(batches), grad_accum, batches_per_epoch)
+    losses, t = [], 0
+    for i, (batch, sync) in enumerate(zip(batches, flags)):
+        if not sync:
+            with torch.no_grad():
+                losses.append(float(loss_fn(sd, batch)))
+            continue
+        t += 1
+        loss, _, sd = train_step(lambda s: loss_fn(s, batch) / grad_accum, sd, state, t, lr_fn(i), weight_decay, grad_clip)
+        losses.append(float(loss) * grad_accum)
+    return losses, flags, sd

@@ -131,3 +131,11 @@ def simple_mae_small():
     ecfg = R.simple_encoder_config(block_size=40, patch_size=24, n_layers=2, dim=64, hidden_dim=128, head_dim=16, n_heads=4, n_kv_heads=4)
     mcfg = R.simple_mae_config(n_layers=2, dim=48, hidden_dim=96, head_dim=8, n_heads=4, n_kv_heads=4)
     return ecfg, mcfg
+
+
+def train_accum(n_items: int = 10):
+    """Dataset of the grad_accum fixture (tests/golden/train_accum.npz): sample i -> (x_i, y_i)."""
+    cfg, _, _ = bf_l1_small()
+    xs = t(synth.make_inputs(n_items, 32, 16, seed=synth.SEED_INPUT + 17))
+    ys = t(synth.make_motion_targets(n_items, 8, 12, seed=synth.SEED_INPUT + 18))
+    return cfg, xs, ys

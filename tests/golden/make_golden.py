@@ -386,12 +386,79 @@ def vq_golden():
          **{"grad/decoder." + k: v.numpy() for k, v in grads_of(net.decoder).items()})
 
 
+def accum_golden():
+    """The reference's REAL hot loop — utils/train_utils.py:93-185 run_train_model under accelerate, CPU, fp32 — with
+    grad_accum = 2 on the small L1 BrainFormer: pins what gradient accumulation means in the reference (accelerate's
+    AcceleratedOptimizer.zero_grad / .step act only on sync micro-steps, and the loop zeroes BEFORE the forward, :134).
+    The loop never returns (the `break` at :185 leaves only the `for`), so the run is ended from a forward pre-hook after
+    N_FWD forwards.  Stored: the sample indices of every micro-batch in the order the loader produced them, the loss of every
+    forward, a parameter checksum at the entry of every forward (says WHEN updates happened) and the parameters at the end."""
+    import tempfile
+    bf, g2, tu = import_reference()
+    N_FWD, N_ITEMS = 12, 10
+    enc = bf.MAEConfig(window_size=32, n_electrodes=16, patch_size=4, dim=64, n_layers=2, head_dim=16,
+                       hidden_dim=128, n_heads=4, n_kv_heads=4)
+    cfg = bf.Config(encoder=enc, n_output_tokens=8, output_dim=12, dim=64, n_layers=2, head_dim=8,
+                    hidden_dim=96, n_heads=4, n_kv_heads=4)
+    m = bf.BrainFormer(cfg).float()
+    load_synth(m)
+    xs = torch.from_numpy(synth.make_inputs(N_ITEMS, 32, 16, seed=synth.SEED_INPUT + 17))
+    ys = torch.from_numpy(synth.make_motion_targets(N_ITEMS, 8, 12, seed=synth.SEED_INPUT + 18))
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self):
+            self.log = []
+
+        def __len__(self):
+            return N_ITEMS
+
+        def __getitem__(self, i):
+            self.log.append(int(i))
+            return xs[i], ys[i], 0
+
+    class Stop(BaseException):
+        pass
+
+    losses, sums = [], []
+    probe = m.encoder.transformer.h[0].attn.qw.weight
+
+    def pre(_mod, _args, _kw=None):
+        if len(sums) == N_FWD:
+            raise Stop()
+        sums.append(float(probe.detach().double().sum()))
+
+    def post(_mod, _args, out):
+        losses.append(float(out[0].detach()))
+
+    m.register_forward_pre_hook(pre)
+    m.register_forward_hook(post)
+    tc = tu.TrainConfig(exp_name="accum", batch_size=4, grad_accum=2, learning_rate=1e-3, weight_decay=1e-5, max_steps=10 ** 6,
+                        eval_interval=10 ** 6, use_scheduler=True, warmup_iters=4, lr_decay_iters=20, num_workers=0,
+                        pin_memory=False, grad_clip=1.0, mixed_precision=False)
+    tr, va = DS(), DS()
+    import contextlib, io
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            tu.run_train_model(m, (tr, va), tc, "golden", Path(tempfile.mkdtemp()))
+    except Stop:
+        pass
+    assert len(losses) == N_FWD and len(tr.log) >= 2 * N_FWD
+    order = np.array(tr.log[:2 * N_FWD]).reshape(N_FWD, 2)
+    sched = tu.init_lr_scheduler(tc)
+    save("train_accum", order=order, losses=np.array(losses), probe_sums=np.array(sums),
+         lrs=np.array([sched(i) for i in range(N_FWD)]), n_items=np.array(N_ITEMS),
+         **{"param/" + k: v.detach().numpy() for k, v in params_of(m).items()})
+
+
 if __name__ == "__main__":
     if os.environ.get("FK_GOLDEN_ONLY") == "pipeline":
         pipeline_golden()
     elif os.environ.get("FK_GOLDEN_ONLY") == "vq_conv_small":
         vq_golden()
+    elif os.environ.get("FK_GOLDEN_ONLY") == "train_accum":
+        accum_golden()
     else:
         main()
         pipeline_golden()
         vq_golden()
+        accum_golden()

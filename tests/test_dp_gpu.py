@@ -102,10 +102,13 @@ def _rccl_worker(rank, port, out):
     launched = []
     orig = opt.sync._launch
     opt.sync._launch = lambda b: (launched.append(b), orig(b))[1]
+    opt.sync.measure = True
     x, y = _batch(4)
     for step in range(2):
         tu.train_step(m, (x, y, None), opt, step, cfg)
     torch.cuda.synchronize()
+    import bench                                   # the self-validation block of a multi-GPU bench line, through RCCL
+    out["dp"] = bench.dp_report(opt.sync, opt.arena, torch.device("cuda", 0), 2)
     out["flat"] = opt.arena.flat.detach().cpu().numpy()
     out["launched"] = len(launched)
     out["nbuckets"] = len(opt.sync.buckets)
@@ -118,6 +121,8 @@ def test_rccl_one_rank_group_runs_the_collective_path():
     out = mp.get_context("spawn").Manager().dict()
     mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
     assert out["launched"] == 2 * out["nbuckets"] and out["rccl"]
+    dp = out["dp"]
+    assert dp["param_checksum_equal"] is True and dp["n_buckets"] == out["nbuckets"] and 0.0 <= dp["exposed_comm_ms"] < 50.0
     from frankenstein_amd.utils import train_utils as tu
     m = _build()
     cfg = tu.TrainConfig(mixed_precision=False, use_scheduler=False, learning_rate=1e-3)

@@ -115,6 +115,59 @@ def test_gradsync_gloo_world2_equals_full_batch():
     assert len(out) == 2 * world and max(out.values()) < 1e-6, dict(out)
 
 
+
+def _accum_worker(rank, world, port, out):
+    """accumulate="sum" under DP: the exchange is switched off on the first micro-step (GradSync.enabled, what accelerate's no_sync
+    does) and the buckets go out on the second, carrying the accumulated sum."""
+    import torch.distributed as dist
+    from frankenstein_amd.utils.train_utils import GradSync, ParamArena
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 11), torch.nn.Tanh(), torch.nn.Linear(11, 3))
+    net = mk()
+    arena = ParamArena(net)
+    sync = GradSync(arena, bucket_bytes=4096)
+    x = torch.randn(16, 37, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(16, 3, generator=torch.Generator().manual_seed(2))
+    k = 16 // world
+    xs, ys = x[rank * k:(rank + 1) * k], y[rank * k:(rank + 1) * k]
+    launched = []
+    orig = sync._launch
+    sync._launch = lambda b: (launched.append(b), orig(b))[1]
+    for ms in range(2):                              # two micro-batches of the rank's shard, loss / grad_accum each
+        sync.enabled = ms == 1
+        h = k // 2
+        (((net(xs[ms * h:(ms + 1) * h]) - ys[ms * h:(ms + 1) * h]) ** 2).mean() / 2).backward()
+        if ms == 0:
+            assert not launched
+    g = arena.grad * sync.finish()
+    ref = mk()
+    ref.load_state_dict(net.state_dict())
+    ((ref(x) - y) ** 2).mean().backward()
+    flat = torch.cat([torch.nn.functional.pad(p.grad.flatten(), (0, (-p.numel()) % 4)) for p in ref.parameters()])
+    out[rank] = float((g - flat).abs().max())
+    out[rank + world] = len(launched) == len(sync.buckets)
+    dist.destroy_process_group()
+
+
+def test_gradsync_gloo_world2_grad_accum_sum():
+    """2 ranks x 2 micro-batches, summed accumulation, mean-reduced == 1 rank x the whole batch; one exchange per window."""
+    import torch.multiprocessing as mp
+    world = 2
+    out = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_accum_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert max(out[0], out[1]) < 1e-6 and out[2] and out[3], dict(out)
+
+
+def test_grad_accumulation_sync_rule_is_accelerates():
+    from frankenstein_amd.utils.train_utils import GradAccumulation
+    acc = GradAccumulation(2)
+    got = [acc.sync(end_of_loader=i % 5 == 4) for i in range(12)]
+    assert got == RT.accum_sync_flags(12, 2, 5) == [False, True, False, True, True, False, True, False, True, True, False, True]
+    one = GradAccumulation(1)
+    assert all(one.sync() for _ in range(3))
+
 def test_param_arena_views_and_padding():
     from frankenstein_amd.utils.train_utils import ParamArena
     net = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
@@ -266,6 +319,11 @@ def test_bench_self_launch_dry_run_world2():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["dry_run"] and out["n_gpus"] == 2 and out["world"] == 2 and out["steps"] == 3 and out["max_rank_time_s"] == 0.002
+    # the data-parallel self-checks of the real run (bench.dp_report), exercised over gloo: replicas that started from different
+    # seeds end with identical parameter checksums, the exchange was measured, its bucket layout is reported, RCCL's CU share capped
+    dp = out["dp"]
+    assert dp["param_checksum_equal"] is True and dp["world"] == 2 and dp["n_buckets"] >= 2 and len(dp["bucket_mb"]) == dp["n_buckets"]
+    assert dp["exposed_comm_ms"] >= 0.0 and out["nccl_max_nchannels"] == "8"
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "AssertionError" not in r.stderr

@@ -210,3 +210,25 @@ def test_simple_mae_small(golden):
     rec = torch.zeros_like(x).index_put((br, masked), pred.detach()).index_put((br, unmasked), x[br, unmasked])
     np.testing.assert_allclose(rec.numpy(), z["recon"], atol=2e-5)
     check_grads(grads(loss, sd), z)
+
+
+def test_train_loop_grad_accum_matches_reference_run(golden):
+    """The reference's run_train_model under accelerate with grad_accum = 2 (golden produced by running that loop itself): the
+    oracle's restatement — update on sync micro-steps only, from that micro-batch's gradient / grad_accum — reproduces the loss of
+    every forward, the micro-steps at which the parameters changed, and the final parameters."""
+    z = golden("train_accum")
+    cfg, xs, ys = C.train_accum(int(z["n_items"]))
+    order = z["order"]
+    batches = [(xs[torch.from_numpy(o)], ys[torch.from_numpy(o)]) for o in order]
+    sd0 = C.state(R.brainformer_shapes(cfg, "to_motion"))
+    lrs = z["lrs"]
+    bpe = int(z["n_items"]) // order.shape[1]
+    losses, flags, sd = RT.train_loop_accum(lambda s, b: R.brainformer_l1(s, b[0], b[1], cfg)[0], sd0, batches, 2, bpe,
+                                            lambda i: float(lrs[i]))
+    np.testing.assert_allclose(losses, z["losses"], rtol=3e-5)
+    # the parameter checksum at the entry of forward i+1 differs from the one at forward i exactly after a sync micro-step
+    changed = [bool(a != b) for a, b in zip(z["probe_sums"][:-1], z["probe_sums"][1:])]
+    assert changed == flags[:-1] and flags == RT.accum_sync_flags(len(flags), 2, bpe)
+    assert flags == [False, True, False, True, True, False, True, False, True, True, False, True]
+    for k, v in sd.items():
+        np.testing.assert_allclose(v.numpy(), z["param/" + k], rtol=2e-4, atol=3e-5, err_msg=k)
