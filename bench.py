@@ -74,25 +74,48 @@ def host_cores() -> int:
     return n
 
 
+def _mem_available_gb() -> float:
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 2 ** 20
+    except Exception:
+        pass
+    return 0.0
+
+
 def cpu_baseline(steps=2):
-    """Oracle (port of the reference CPU path) fwd+bwd+clip+AdamW at cfg2, B=1, fp32, all host threads."""
+    """Oracle (port of the reference CPU path) fwd+bwd+clip+AdamW at cfg2, fp32, all host threads: B=1 (1 warm-up + best of `steps`)
+    and, where the host has the memory for the dense-mask math path (SURVEY 8d asks for B=1 and B=4; B=4 keeps ~60 GB of fp32 score
+    tensors alive for the backward), one step at B=4.  `value` is the better per-frame rate of the two."""
     torch.set_num_threads(host_cores())
     from oracle import ref_models as R
     from oracle import ref_train as RT
     from tests import cases as C
-    cfg, x, tgt = C.cfg2(1)
-    sd = C.state(R.brainformer_shapes(cfg, "to_motion"))
-    state, cur = {}, sd
-    loss_fn = lambda s: R.brainformer_l1(s, x, tgt, cfg)[0]
-    times = []
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        _, _, cur = RT.train_step(loss_fn, cur, state, i + 1, 1e-3)
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {"value": round(600 / best, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"cfg2 brainformer-small at B=1 (600 frames/step), fp32, 1 warm-up + best of {steps} steps, "
-                      f"fwd+bwd+clip+AdamW, {best:.2f} s/step"}
+
+    def run(B, n_steps, warm):
+        cfg, x, tgt = C.cfg2(B)
+        sd = C.state(R.brainformer_shapes(cfg, "to_motion"))
+        state, cur = {}, sd
+        loss_fn = lambda s: R.brainformer_l1(s, x, tgt, cfg)[0]
+        times = []
+        for i in range(n_steps + warm):
+            t0 = time.perf_counter()
+            _, _, cur = RT.train_step(loss_fn, cur, state, i + 1, 1e-3)
+            times.append(time.perf_counter() - t0)
+        return min(times[warm:])
+
+    best1 = run(1, steps, 1)
+    samples = [{"batch": 1, "s_per_step": round(best1, 2), "frames_per_s": round(600 / best1, 2)}]
+    if _mem_available_gb() > 150.0:
+        t4 = run(4, 1, 0)
+        samples.append({"batch": 4, "s_per_step": round(t4, 2), "frames_per_s": round(2400 / t4, 2)})
+    best = max(samples, key=lambda d: d["frames_per_s"])
+    return {"value": best["frames_per_s"], "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"cfg2 brainformer-small, fp32, fwd+bwd+clip+AdamW on the host cores: B=1 (600 frames/step), 1 warm-up + best of {steps} steps"
+                      + (", and one step at B=4 (2400 frames/step, threads already warm)" if len(samples) > 1 else "")
+                      + f"; value = the better per-frame rate (B={best['batch']}, {best['s_per_step']} s/step)",
+            "samples": samples}
 
 
 def mfma_util_pmc():

@@ -56,7 +56,7 @@ SIGNATURES = {
     "fk_gpt_embed_step": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p]),
     "fk_kv_append": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p]),
     "fk_attn_decode": (_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _f32, _int, _p]),
-    "fk_sample_topk": (_int, [_p, _i64, _i64, _i64, _f32, _i64, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "fk_sample_topk": (_int, [_p, _i64, _i64, _i64, _f32, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     "fk_im2col1d": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_col2im1d": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_elu_fwd": (_int, [_p, _p, _i64, _int, _p]),

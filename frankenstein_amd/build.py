@@ -14,7 +14,13 @@ SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_opt
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950 has a unified file), which removes the
 # v_accvgpr_read/write traffic between the matrix results and the softmax / epilogue VALU code.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
+# -fno-slp-vectorize: hipcc's SLP vectorizer turns scalar fp32 pairs (the RoPE rotations x0*c - x1*s, x0*s + x1*c) into
+# v_pk_mul_f32 -> v_pk_fma_f32 chains with op_sel half-swaps.  On MI355X those chains returned a WRONG low-half result in lanes 48-63
+# whenever waves of another kernel (the small bf16 weight-gradient GEMM: ds_read_b64_tr_b16 + v_mfma) shared the SIMD -- in the dQ / dK
+# store of fk_attn_bwd, in the QKV projection's RoPE epilogue and in the plain elementwise fk_rope alike (all operands defined, waits
+# irrelevant, the quiet result exact: DESIGN.md 5.4, tools/coresidency_sweep.py).  Scalar code is exact beside the same occupant and no
+# slower (51.7 ms/step either way).  Hand-written f32x2 arithmetic (no half-swaps) is unaffected and stays.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-fno-slp-vectorize",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 

@@ -283,6 +283,9 @@ FK_DEV void store_rows_T_rope(T* base, int64_t rs, int row, bool row_ok, const f
       const int d = dt * 32 + 8 * g + 4 * lh;
       if (d < D) {
         const f32x4 cs = *reinterpret_cast<const f32x4*>(table + d);   // (c0, s0, c1, s1) for pairs d/2, d/2+1
+#ifdef FK_ROPE_EPI_NOPS
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");
+#endif
         const float a0 = acc[dt][4 * g] * mul, a1 = acc[dt][4 * g + 1] * mul, a2 = acc[dt][4 * g + 2] * mul, a3 = acc[dt][4 * g + 3] * mul;
         const float o0 = a0 * cs[0] + a1 * cs[1], o1 = -a0 * cs[1] + a1 * cs[0];
         const float o2 = a2 * cs[2] + a3 * cs[3], o3 = -a2 * cs[3] + a3 * cs[2];
@@ -1463,6 +1466,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_asm_kernel(AttnArgs p) {
   FK_LIFE_END(3)
 }
 constexpr size_t FWD_ASM_LDS = 2 * 4 * 64 * 128 + 16;
+static_assert(FWD_ASM_LDS <= 160 * 1024, "LDS of a CU");
 #endif
 
 #ifndef FK_NO_DQ_ASM
@@ -1952,6 +1956,8 @@ template <typename T, int D> size_t fwd_lds() {
 }
 template <typename T, int D> size_t dq_lds() { return 4 * BKV * AT<T, D>::RSTRIDE; }
 constexpr size_t DQ_PS_LDS = 6 * BKV * 128, DKDV_PS_LDS = 6 * 64 * 128 + 3 * 2 * 64 * sizeof(float);
+static_assert(DQ_PS_LDS <= 160 * 1024, "LDS of a CU");
+static_assert(DKDV_PS_LDS <= 160 * 1024, "LDS of a CU");
 template <typename T, int D> size_t dkdv_lds() { return 4 * 64 * AT<T, D>::RSTRIDE + 4 * 64 * sizeof(float); }
 
 template <typename K> void allow_lds(K kernel, size_t bytes) {

@@ -122,7 +122,7 @@ template <typename F> FK_DEV float block_reduce(float v, float* red, F op, float
 
 __global__ __launch_bounds__(SAMPLE_THREADS) void sample_topk_kernel(const float* logits, int64_t ld, int V, float inv_temp, int top_k,
                                                                      const unsigned long long* seed, int64_t* step, int32_t* pos_inc,
-                                                                     int64_t* cur, int64_t* out, int64_t out_ld, unsigned* ticket) {
+                                                                     int64_t* cur, int64_t* out, int64_t out_ld, int64_t out_cols, unsigned* ticket) {
   __shared__ unsigned hist[256];
   __shared__ float red[SAMPLE_THREADS / 64];
   __shared__ float scan[SAMPLE_THREADS];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_topk_kernel(const float
         if (f32_sortable(row[i] * inv_temp) >= kth) { w = i; break; }
     }
     cur[b] = w;
-    if (out) out[(int64_t)b * out_ld + my_step] = w;
+    if (out && my_step < out_cols) out[(int64_t)b * out_ld + my_step] = w;       // a step counter past the buffer is not a write past it
     __threadfence();
     if (atomicAdd(ticket, 1u) == gridDim.x - 1) {         // every block has read step[0] and written its token
       ticket[0] = 0u;
@@ -258,11 +258,14 @@ int fk_attn_decode(const void* q, int64_t q_bs, const void* kv, int64_t kv_bs, i
 }
 
 int fk_sample_topk(const float* logits, int64_t ld, int64_t B, int64_t V, float temperature, int64_t top_k, const uint64_t* seed,
-                   int64_t* step, int32_t* pos_inc, int64_t* cur, int64_t* out, int64_t out_ld, uint32_t* ticket, void* stream) {
+                   int64_t* step, int32_t* pos_inc, int64_t* cur, int64_t* out, int64_t out_ld, int64_t out_cols, uint32_t* ticket,
+                   void* stream) {
+  FK_CHECK_ARG(out == nullptr || (out_cols > 0 && out_cols <= out_ld), "fk_sample_topk: out given without its width (out_cols=%lld, out_ld=%lld)",
+               (long long)out_cols, (long long)out_ld);
   FK_CHECK_ARG(logits && seed && step && cur && ticket && B > 0 && B < 65536 && V > 0 && V < (1LL << 31) && ld >= V && temperature > 0.0f,
                "fk_sample_topk: bad arguments (B=%lld V=%lld temperature=%g)", (long long)B, (long long)V, (double)temperature);
   hipLaunchKernelGGL(sample_topk_kernel, dim3((unsigned)B), dim3(SAMPLE_THREADS), 0, (hipStream_t)stream, logits, ld, (int)V, 1.0f / temperature,
-                     (int)(top_k > 0 && top_k < V ? top_k : 0), (const unsigned long long*)seed, step, pos_inc, cur, out, out_ld, ticket);
+                     (int)(top_k > 0 && top_k < V ? top_k : 0), (const unsigned long long*)seed, step, pos_inc, cur, out, out_ld, out_cols, ticket);
   FK_CHECK_LAUNCH("fk_sample_topk");
   return FK_OK;
 }

@@ -755,6 +755,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs p) {
 // and A(g+1) stays in flight across the barrier, so the memory pipe never drains.  The epilogue stages through the A and B slots
 // just computed (4 waves each).  LDS = 96 + 64 KiB.
 constexpr int R2_A = 256 * ROW_BYTES, R2_LDS = 5 * R2_A;
+static_assert(R2_LDS <= 160 * 1024, "LDS of a CU");
 
 template <typename TO, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
@@ -877,6 +878,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring2_kernel(NtArgs p) {
 // bytes for the same product.  Rings as in the 256 x 256 kernel (A: three 32-KiB slots, two stages ahead; B: two 24-KiB slots, one ahead;
 // counted wait vmcnt(4)); every wave owns 32 rows and all 192 columns (6 accumulator tiles), so the epilogue is three 64-column sweeps.
 constexpr int R192_A = 256 * ROW_BYTES, R192_B = 192 * ROW_BYTES, R192_LDS = 3 * R192_A + 2 * R192_B + 8192;
+static_assert(R192_LDS <= 160 * 1024, "LDS of a CU");
 
 template <typename TO, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_ring192_kernel(NtArgs p) {

@@ -52,9 +52,10 @@ def bump_weight_epoch() -> None:
 # accumulated straight into the arena (no temporary, no autograd add).  Optionally (FusedAdamW(overlap_wgrad=True) or
 # FK_WGRAD_STREAM=1) they run on a SECOND HIP stream beside the dX chain; the optimizer joins that stream before the update and
 # DP buckets are all-reduced from it (GradSync).  OFF by default: the large-tile GEMMs are one 128-KiB-LDS block per CU, and two
-# such grids from two streams split the CUs unevenly — measured 65 ms steps turning into 80-160 ms ones at random.
+# such grids from two streams split the CUs unevenly — measured 65 ms steps turning into 80-160 ms ones at random.  (The run-to-run
+# differences round 2 saw in this mode were not the stream's doing: compiler-packed fp32 in the RoPE epilogues beside ANY co-resident
+# bf16 GEMM, fixed in the build flags — DESIGN.md 5.4, tests/test_coresidency_gpu.py.)
 _WGRAD_STREAM = None
-_CAPTURE = None       # diagnostics (tools/wgrad_stream_probe.py): a list that receives the tensors of every AttnBranch.backward
 
 
 def enable_wgrad_stream(on: bool = True):
@@ -402,9 +403,6 @@ class AttnBranch(torch.autograd.Function):
         qkv3, dqkv3 = qkv.view(B, N, 3 * HD), dqkv.view(B, N, 3 * HD)
         q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
         dq, dk, dv = (dqkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
-        pre = None
-        if _CAPTURE is not None:
-            pre = {"qkv_pre": qkv.clone(), "o_pre": o.clone(), "do_pre": do.clone(), "lse_pre": lse.clone()}
         if rope is not None and D % 4 == 0:       # inverse RoPE fused into the dQ / dK stores
             K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask, rope_table=rope.table, rope_off=rope.pos_off(N),
                        q_prescaled=ctx.prescale)
@@ -412,8 +410,6 @@ class AttnBranch(torch.autograd.Function):
             K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask)
             if rope is not None:
                 K.rope_(dqkv3, 2 * H, D, rope.table, rope.pos_off(N), conj=True)
-        if _CAPTURE is not None:        # main-stream copies: stream order kept, no device synchronisation (which would hide timing effects)
-            _CAPTURE.append({"qkv": qkv.clone(), "o": o.clone(), "do": do.clone(), "lse": lse.clone(), "dqkv": dqkv.clone(), "dy": dy2.clone(), **pre})
         dh = K.gemm_nt(dqkv, shadow(qkv_w, transpose=True))
         dws = wgrad(dqkv, h, list(qkv_w))
         dqb = K.colsum(dqkv) if has_qb else None

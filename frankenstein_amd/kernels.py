@@ -474,14 +474,14 @@ def sample_topk(logits: Tensor, temperature: float, top_k: Optional[int], state:
     if cur is None:
         cur = torch.empty(B, dtype=torch.int64, device=logits.device)
     assert cur.dtype == torch.int64 and cur.is_contiguous() and cur.numel() == B
-    out_ld = 0
+    out_ld = out_cols = 0
     if out is not None:
         assert out.dtype == torch.int64 and out.dim() == 2 and out.shape[0] == B and out.stride(1) == 1
-        out_ld = out.stride(0)
+        out_ld, out_cols = out.stride(0), out.shape[1]          # the kernel stops writing at column out_cols, whatever the step counter says
     if pos_inc is not None:
         assert pos_inc.dtype == torch.int32 and pos_inc.numel() == 1
     call("fk_sample_topk", logits.data_ptr(), logits.stride(0), B, V, float(temperature), int(top_k or 0), state.seed.data_ptr(),
-         state.step.data_ptr(), _ptr(pos_inc), cur.data_ptr(), _ptr(out), out_ld, state.ticket.data_ptr(), _stream())
+         state.step.data_ptr(), _ptr(pos_inc), cur.data_ptr(), _ptr(out), out_ld, out_cols, state.ticket.data_ptr(), _stream())
     return cur
 
 

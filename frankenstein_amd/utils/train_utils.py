@@ -252,13 +252,8 @@ class FusedAdamW:
                  eps: float = 1e-8, grad_clip: Optional[float] = None, group=None, bucket_bytes: int = 8 << 20,
                  overlap_wgrad: Optional[bool] = None, sync_always: bool = False):
         self.arena = ParamArena(model)
-        env_on = os.environ.get("FK_WGRAD_STREAM", "0") == "1"
         if overlap_wgrad is None:
-            overlap_wgrad = env_on                                             # see engine.py: off by default
-        if overlap_wgrad and not env_on:
-            # EXPERIMENTAL: with the weight-gradient side stream on, gradients were observed to differ run to run on ragged shapes
-            # (DESIGN.md §5.1); the mode is not part of the supported surface until that is explained
-            raise RuntimeError("overlap_wgrad is experimental (run-to-run differences, DESIGN.md): set FK_WGRAD_STREAM=1 to opt in")
+            overlap_wgrad = os.environ.get("FK_WGRAD_STREAM", "0") == "1"        # off by default: see engine.py (no speed-up with one-block-per-CU grids)
         if overlap_wgrad and self.arena.flat.is_cuda and E.wgrad_stream() is None:
             E.enable_wgrad_stream(True)
         self.m = torch.zeros_like(self.arena.flat)

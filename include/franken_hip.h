@@ -162,11 +162,13 @@ int fk_attn_decode(const void* q, int64_t q_bs, const void* kv, int64_t kv_bs, i
                    int64_t B, int64_t H, int64_t D, float scale, int dtype, void* stream);
 /* fk_sample_topk: the sampling tail of GPT.generate (models/gpt2_model.py:340-351) as one launch: logits[b,:] / temperature, top-k
  * crop (values below the k-th largest -> -inf; top_k <= 0: none), softmax, ONE multinomial draw per row by inverse CDF with a
- * Philox4x32-10 uniform keyed by (*seed; *step, b).  Writes the token to cur[b] and, if out != NULL, to out[b*out_ld + *step]; the last
+ * Philox4x32-10 uniform keyed by (*seed; *step, b).  Writes the token to cur[b] and, if out != NULL and *step < out_cols, to out[b*out_ld + *step] (out is [B, out_cols] with row
+ * stride out_ld: a reused state or one graph replay too many cannot write past it; out != NULL needs 0 < out_cols <= out_ld); the last
  * block to finish sets *step += 1 and, if pos_inc != NULL, *pos_inc += 1 (so a captured decode graph advances by itself).  logits fp32,
  * `ticket` a zero-initialised uint32 scratch word owned by the caller.  top_k = 1 is the deterministic argmax (first maximum).        */
 int fk_sample_topk(const float* logits, int64_t ld, int64_t B, int64_t V, float temperature, int64_t top_k, const uint64_t* seed,
-                   int64_t* step, int32_t* pos_inc, int64_t* cur, int64_t* out, int64_t out_ld, uint32_t* ticket, void* stream);
+                   int64_t* step, int32_t* pos_inc, int64_t* cur, int64_t* out, int64_t out_ld, int64_t out_cols, uint32_t* ticket,
+                   void* stream);
 
 /* ---- VQ-VAE tokenizer convolutions (models/vq_brain.py), channels-last [B, T, C], causal left padding dil*(K-1):
  * fk_im2col1d: cols[b, t, k, :] = x[b, t*stride + k*dil - pad, :] (zeros outside), Tout = (T-1)/stride + 1, so that

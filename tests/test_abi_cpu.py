@@ -54,6 +54,9 @@ def test_argument_validation_needs_no_gpu(built):
     assert rc == -1 and b"FK_ATTN_Q_PRESCALED" in lib.fk_last_error()
     rc = lib.fk_patchify(16, 16, 1, 10, 4, 3, 8, 0, None)
     assert rc == -1
+    # fk_sample_topk: an output buffer without its width is refused (the device-side step counter is not trusted to stay inside it)
+    rc = lib.fk_sample_topk(16, 8, 1, 8, 1.0, 0, 16, 16, None, 16, 16, 4, 0, 16, None)
+    assert rc == -1 and b"out_cols" in lib.fk_last_error()
 
 
 def test_integration_snippet_matches_the_binding():

@@ -1,0 +1,73 @@
+"""What hipcc compiled the hand-scheduled kernels into (CPU suite: hipcc cross-compiles gfx950 without a GPU).
+
+The generated attention streams (csrc/attn_*_asm.inc) name their temporaries as clobbers and leave accumulators, fragments and
+addresses to hipcc; the ring-buffered GEMMs are written for two waves per SIMD.  A compiler update that spills inside a matrix loop or
+needs more than 256 registers would only show up as a slow benchmark: this test holds the device code of attention.hip and gemm.hip to
+the bounds DESIGN.md documents (tools/kernel_resources.py prints the whole table).  The LDS budgets are static_asserts in the sources."""
+import pytest
+
+from tools import kernel_resources as KR
+
+# kernel-name fragment -> (max VGPRs, min waves/SIMD, max scratch bytes per lane, scratch instructions allowed inside ANY loop that holds MFMAs).
+# In every kernel the hot loop (the innermost loop with the most MFMAs) must be free of scratch traffic.  attn_fwd_asm_kernel is the one
+# kernel with spill traffic inside (cold) loops: the classic-softmax phase and the at most three steps that align the tile counter to the
+# four-step steady loop move the 16 carried scores through scratch (84 bytes per lane); the steady loop itself (64 MFMAs per trip) has none.
+BOUNDS = {
+    "attn_bwd_dq_asm_kernel": (256, 2, 0, 0),
+    "attn_bwd_dkdv_asm_kernel": (256, 2, 20, 0),
+    "attn_fwd_asm_kernel": (256, 2, 84, 40),
+    "attn_fwd_ps_kernel": (128, 4, 0, 0),
+    "attn_bwd_dq_ps_kernel": (256, 2, 0, 0),
+    "attn_bwd_dkdv_ps_kernel": (256, 2, 0, 0),
+    "gemm_nt_ring2_kernel": (256, 2, 0, 0),
+    "gemm_nt_ring192_kernel": (256, 2, 0, 0),
+    "gemm_nt_ring_kernel": (256, 2, 0, 0),
+    "gemm_tn_big_kernel": (256, 2, 0, 0),
+}
+
+
+@pytest.fixture(scope="module")
+def table(tmp_path_factory):
+    return KR.survey(tmp_path_factory.mktemp("isa"))
+
+
+@pytest.mark.parametrize("frag", sorted(BOUNDS))
+def test_compiled_kernel_stays_inside_its_register_and_spill_budget(table, frag):
+    max_vgpr, min_occ, max_spill, max_inloop = BOUNDS[frag]
+    hits = {n: r for n, r in table.items() if frag in n}
+    assert hits, f"no kernel named *{frag}* in the compiled sources"
+    for name, r in hits.items():
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= max_vgpr, (name, r)
+        assert r["Occupancy"] >= min_occ, (name, r)
+        # SGPR spills go to VGPR lanes (v_writelane), not to memory; only the one-body comparison kernel gemm_nt_ring2_kernel<.., -1>
+        # (FK_NT_RING2_GENERIC=1, not used by default) has any
+        assert r["ScratchSize"] <= max_spill and r["SGPRs Spill"] <= (24 if "ring2_kernel" in name and "Lin1E" in name else 0), (name, r)
+        loops = KR.mfma_loops(r["_asm"], name)
+        inloop = max((l[3] for l in loops), default=0)
+        assert inloop <= max_inloop, f"{name}: {inloop} scratch loads/stores inside a loop that contains MFMAs"
+        hot = KR.hot_loop(loops)
+        assert hot is None or hot[3] == 0, f"{name}: scratch traffic in the hot loop {hot}"
+        if "asm_kernel" in frag:
+            assert hot is not None and hot[2] >= 24, (name, hot)          # the generated tile step(s) are in that loop
+
+
+def test_lds_budgets_are_static_asserts():
+    """160 KiB of LDS per CU: every large dynamic allocation is checked at compile time in the source itself"""
+    from frankenstein_amd import build as B
+    att, gem = (B.CSRC / "attention.hip").read_text(), (B.CSRC / "gemm.hip").read_text()
+    for sym in ("FWD_ASM_LDS", "DQ_PS_LDS", "DKDV_PS_LDS"):
+        assert f"static_assert({sym} <= 160 * 1024" in att, sym
+    for sym in ("R2_LDS", "R192_LDS"):
+        assert f"static_assert({sym} <= 160 * 1024" in gem, sym
+
+
+def test_no_compiler_packed_fp32_with_half_swaps(table):
+    """v_pk_*_f32 with op_sel / op_sel_hi half-swaps is what hipcc's SLP vectorizer makes of scalar fp32 pairs; those chains returned
+    wrong low-half results in lanes 48-63 beside a co-resident GEMM.  The build switches the vectorizer off; hand-written
+    f32x2 arithmetic (no half-swaps) stays."""
+    import re
+    from frankenstein_amd import build as B
+    assert "-fno-slp-vectorize" in B.FLAGS
+    for asm in {str(r["_asm"]) for r in table.values()}:
+        bad = [l for l in open(asm) if re.search(r"v_pk_(mul|fma|add)_f32.*op_sel", l)]
+        assert not bad, (asm, bad[:3])

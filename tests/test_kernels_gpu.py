@@ -779,3 +779,10 @@ def test_sample_topk_on_device(K):
     for b in range(B):
         cnt = torch.bincount(full[b], minlength=V).double()
         assert 0.5 * float((cnt / 4000 - pf[b].double()).abs().sum()) < 0.25
+    # a step counter that has run past the output buffer (a reused state, one graph replay too many) must not write past it
+    st4 = K.SampleState(lg.device, seed=9)
+    buf = torch.full((B, 8), -7, dtype=torch.int64, device="cuda")
+    small = buf[:, :3]                                                  # [B, 3] view, row stride 8: columns 3.. are NOT the kernel's
+    for _ in range(6):
+        K.sample_topk(lg, T, k, st4, cur=cur, out=small)
+    assert int(st4.step) == 6 and bool((buf[:, 3:] == -7).all()) and bool((buf[:, :3] >= 0).all())

@@ -773,16 +773,42 @@ def test_vq_plus_brainformer_pipeline_bf16():
         fa.set_compute_dtype("fp32")
 
 
-def test_overlap_wgrad_is_opt_in_only(monkeypatch):
-    """The weight-gradient side stream is experimental (run-to-run differences on ragged shapes): asking for it without
-    the FK_WGRAD_STREAM=1 opt-in is an error, not a silently different numerical mode."""
+def test_overlap_wgrad_gives_the_same_bits():
+    """The weight-gradient side stream (FusedAdamW(overlap_wgrad=True) / FK_WGRAD_STREAM=1: dW GEMMs beside the dX chain) changes where
+    kernels run, not what they compute: on the ragged shape where round 2 saw run-to-run differences (compiler-packed fp32 in the RoPE
+    epilogues beside a co-resident GEMM) two runs with the stream on and one with it off end with identical parameters."""
+    from frankenstein_amd import engine as E
+    from frankenstein_amd.models import brainformer as bf
     from frankenstein_amd.utils import train_utils as tu
-    monkeypatch.delenv("FK_WGRAD_STREAM", raising=False)
-    with pytest.raises(RuntimeError, match="experimental"):
-        tu.FusedAdamW(torch.nn.Linear(8, 8).cuda(), overlap_wgrad=True)
+    fa.set_compute_dtype("bf16")
+    try:
+        enc = bf.MAEConfig(window_size=475, n_electrodes=256, patch_size=25, dim=320, n_layers=2, head_dim=64, hidden_dim=840,
+                           n_heads=5, n_kv_heads=5)
+        cfg = bf.Config(encoder=enc, n_output_tokens=9, output_dim=70, dim=320, n_layers=1, head_dim=64, hidden_dim=328,
+                        n_heads=5, n_kv_heads=5)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.randn(3, 475, 256, device="cuda", generator=g)
+        y = torch.randn(3, 9, 70, device="cuda", generator=g)
+        outs = []
+        for overlap in (False, True, True):
+            torch.manual_seed(0)
+            m = bf.BrainFormer(cfg).cuda()
+            opt = tu.FusedAdamW(m, lr=2e-3, weight_decay=0.0, grad_clip=1.0, overlap_wgrad=overlap)
+            assert (E.wgrad_stream() is not None) == overlap
+            tc = tu.TrainConfig(mixed_precision=True, use_scheduler=False, learning_rate=2e-3)
+            losses = [float(tu.train_step(m, (x, y, None), opt, s, tc)) for s in range(3)]
+            torch.cuda.synchronize()
+            outs.append((losses, opt.arena.flat.detach().clone()))
+            E.enable_wgrad_stream(False)
+        for losses, flat in outs[1:]:
+            assert losses == outs[0][0] and torch.equal(flat, outs[0][1])
+    finally:
+        E.enable_wgrad_stream(False)
+        fa.set_compute_dtype("fp32")
 
 
-def test_graphed_train_step_is_bit_identical_to_eager(overlap=False):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_graphed_train_step_is_bit_identical_to_eager(overlap):
     """train_utils.GraphedTrainStep (forward + backward replayed from one hipGraph, update eager) against train_step on
     the same seeded batches with a cosine schedule: same losses and same parameters bit for bit after 5 steps; a batch of
     another shape is refused."""

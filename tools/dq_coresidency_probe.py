@@ -174,7 +174,10 @@ def report(name, got, rep):
 
 SENT = 0.0
 total = {}
+OCCS = os.environ.get("PROBE_OCC", "tn,copy,valu,nt").split(",")
 for name, occ in (("tn", occ_tn), ("copy", occ_copy), ("valu", occ_valu), ("nt", occ_nt)):
+    if name not in OCCS:
+        continue
     cnt = 0
     for rep in range(REPS):
         SENT = 11.0 + rep

@@ -1,4 +1,6 @@
-"""Which parameters differ between two identical bf16 training runs when the weight-gradient side stream is on (FK_WGRAD_STREAM=1)?"""
+"""Which parameters differ between two identical bf16 training runs when the weight-gradient side stream is on (FK_WGRAD_STREAM=1)?
+(The operand-capture mode of round 2 is gone: tools/dq_coresidency_probe.py replays the attention backward itself, tools/coresidency_sweep.py
+every kernel, beside a concurrent GEMM.)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("FK_WGRAD_STREAM", "1")
@@ -20,7 +22,6 @@ if os.environ.get("PROBE_CFG2"):                     # the benchmark's dimension
     y = torch.randn(2, 32, 64, device="cuda", generator=g)
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 runs = []
-caps = []
 from frankenstein_amd import engine as E
 for rep in range(3):
     torch.manual_seed(0)
@@ -31,14 +32,9 @@ for rep in range(3):
         if os.environ.get("PROBE_SYNC"):
             # the step split by hand with a full device sync between backward and update
             for gq in opt.param_groups: gq['lr'] = 2e-3
-            if os.environ.get("PROBE_CAPTURE"):      # keep the operands / results of every attention backward of this run
-                E._CAPTURE = []
             loss, _ = m(x, y, date_info=None)
             loss.backward()
             torch.cuda.synchronize()
-            if E._CAPTURE is not None:
-                caps.append(E._CAPTURE)
-                E._CAPTURE = None
             if os.environ.get("PROBE_GRADS"):        # compare the gradients themselves instead of the updated parameters
                 runs.append({k: v.grad.detach().clone() for k, v in m.named_parameters()})
                 break
@@ -53,32 +49,4 @@ for k in runs[0]:
     if any(d):
         md = max(float((runs[0][k] - runs[r][k]).abs().max()) for r in (1, 2))
         print(f"{k:60s} differing elements vs run 0: {d}  of {runs[0][k].numel()}  max |diff| {md:.3e}  (max |value| {float(runs[0][k].abs().max()):.3e})")
-if caps:
-    # which operand of which attention backward differs between run 0 and the others?  (index 0 = first backward executed = last layer)
-    for r in range(1, len(caps)):
-        for i, (a, b) in enumerate(zip(caps[0], caps[r])):
-            for key in a:
-                nd = int((a[key] != b[key]).sum())
-                if nd:
-                    d = (a[key].float() - b[key].float()).abs()
-                    idx = (a[key] != b[key]).nonzero()
-                    cols = sorted(set(idx[:, -1].tolist()))[:24]
-                    rows = sorted(set(idx[:, 0].tolist()))[:12] if idx.shape[1] > 1 else []
-                    print(f"run {r} vs 0: attention backward #{i}: {key} differs in {nd} of {a[key].numel()} elements, max |diff| {float(d.max()):.3e}; "
-                          f"last-dim indices {cols}{'...' if len(cols) == 24 else ''}; first-dim indices {rows}")
-    # did an operand change WHILE the attention backward ran (clone before the launch vs clone after it, same run)?
-    for r, cap in enumerate(caps):
-        for i, c in enumerate(cap):
-            for key in ("qkv", "o", "do", "lse"):
-                nd = int((c[key] != c[key + "_pre"]).sum())
-                if nd:
-                    print(f"run {r}: attention backward #{i}: {key} changed during the call in {nd} elements")
-if caps:
-    # did an operand change WHILE the attention backward ran (clone before the launch vs clone after it, same run)?
-    for r, cap in enumerate(caps):
-        for i, c in enumerate(cap):
-            for key in ("qkv", "o", "do", "lse"):
-                nd = int((c[key] != c[key + "_pre"]).sum())
-                if nd:
-                    print(f"run {r}: attention backward #{i}: {key} changed during the call in {nd} elements")
 print("done")
