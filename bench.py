@@ -35,12 +35,23 @@ MFMA_PEAK_BF16 = 2.5e15          # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF
 FLOP_PER_FRAME = 1.8173e9        # cfg2 fwd+bwd algorithmic FLOPs per input frame (visible attention only)
 
 
-def cfg2_model(dtype="bf16"):
+def cfg2_model(dtype="bf16", head="l1"):
+    """head 'l1': the file-class BrainFormer (32 output tokens x 128, L1 loss) — the headline workload.  head 'ce': cfg2's CE variant
+    (the notebook CE BrainFormer, 25 output tokens, V = 50257, cross entropy with -100 padding) with the fused head loss
+    (train_utils.enable_fused_head_loss: the reference's training loop only uses the loss, utils/train_utils.py:138-139)."""
     import frankenstein_amd as fa
     from frankenstein_amd.models import brainformer as bf
     fa.set_compute_dtype(dtype)
     enc = bf.MAEConfig(window_size=600, n_electrodes=256, patch_size=25, dim=384, n_layers=6, head_dim=64,
                        hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    if head == "ce":
+        from frankenstein_amd.models.notebook_models import BrainFormerCE
+        from frankenstein_amd.utils import train_utils as tu
+        cfg = bf.Config(encoder=enc, n_output_tokens=25, output_dim=50257, dim=384, n_layers=2, head_dim=64,
+                        hidden_dim=768, n_heads=6, n_kv_heads=6)
+        m = BrainFormerCE(cfg)
+        tu.enable_fused_head_loss(m)
+        return m, cfg
     cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=384, n_layers=2, head_dim=64,
                     hidden_dim=768, n_heads=6, n_kv_heads=6)
     return bf.BrainFormer(cfg), cfg
@@ -248,6 +259,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--head", default="l1", choices=["l1", "ce"], help="l1: the headline workload; ce: cfg2's CE-head variant (25 tokens, V = 50257)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true")
     ap.add_argument("--all-timers", action="store_true", help="HIP-event timing of every kernel family (default: the roofline kernel family only)")
@@ -276,7 +288,7 @@ def main():
 
     from frankenstein_amd import kernels as K
     from frankenstein_amd.utils import train_utils as tu
-    model, cfg = cfg2_model(args.dtype)
+    model, cfg = cfg2_model(args.dtype, args.head)
     init_weights(model)
     model.to(dev)
     tcfg = tu.TrainConfig(batch_size=args.batch * world, mixed_precision=(args.dtype == "bf16"), use_scheduler=False,
@@ -287,8 +299,14 @@ def main():
 
     B, T, Cn = args.batch, 600, 256
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pool = [(torch.randn(B, T, Cn, device=dev, generator=g), torch.randn(B, 32, 128, device=dev, generator=g), None)
-            for _ in range(2)]                      # synthetic batches resident in HBM
+    def labels():
+        if args.head == "ce":                       # GPT-2 token ids with a random-length -100 tail
+            tok = torch.randint(0, 50257, (B, 25), device=dev, generator=g)
+            tail = torch.randint(1, 11, (B, 1), device=dev, generator=g)
+            return tok.masked_fill(torch.arange(25, device=dev)[None, :] >= 25 - tail, -100)
+        return torch.randn(B, 32, 128, device=dev, generator=g)
+
+    pool = [(torch.randn(B, T, Cn, device=dev, generator=g), labels(), None) for _ in range(2)]   # synthetic batches resident in HBM
 
     def sync():
         if world > 1:
@@ -350,7 +368,8 @@ def main():
             "n_gpus": world, "world": world, "rccl": (".".join(map(str, torch.cuda.nccl.version())) if world > 1 else None),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "brainformer-small (6L d=384 6x64 heads, N=6144 tokens) + 2-block perceiver, L1 head; "
+            "config": {"workload": "brainformer-small (6L d=384 6x64 heads, N=6144 tokens) + 2-block perceiver, "
+                                   + ("L1 head" if args.head == "l1" else "CE head (25 tokens, V=50257, fused head loss)") + "; "
                                    "fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world, "frames_T": T,
                        "electrodes": Cn, "parallelism": f"dp{world}", "weights": "random-init (seed 42)"},
             "roofline": roof,

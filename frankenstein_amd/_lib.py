@@ -70,6 +70,10 @@ SIGNATURES = {
     "fk_loss_workspace_bytes": (_sz, [_i64]),
     "fk_l1_loss_fwd": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _int, _p, _sz, _p]),
     "fk_l1_loss_bwd": (_int, [_p, _p, _p, _p, _i64, _int, _p, _i64, _p, _int, _p]),
+    "fk_head_ce_workspace_bytes": (_sz, [_i64, _i64]),
+    "fk_head_ce_fwd": (_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _sz, _p]),
+    "fk_head_ce_bwd": (_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
+    "fk_transpose2d": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _p]),
     "fk_ce_workspace_bytes": (_sz, [_i64]),
     "fk_ce_loss_fwd": (_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p, _sz, _p]),
     "fk_ce_loss_bwd": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p]),

@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libfranken_hip.so"
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_optim.hip", "pipeline.hip", "conv.hip", "decode.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_optim.hip", "pipeline.hip", "conv.hip", "decode.hip", "head_ce.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950 has a unified file), which removes the
 # v_accvgpr_read/write traffic between the matrix results and the softmax / epilogue VALU code.
@@ -32,7 +32,7 @@ def _stale(out: Path, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    hdrs = [CSRC / "fk_common.h", HERE.parent / "include" / "franken_hip.h", *sorted(CSRC.glob("*.inc"))]   # *.inc: generated streams (tools/gen)
+    hdrs = [*sorted(CSRC.glob("*.h")), HERE.parent / "include" / "franken_hip.h", *sorted(CSRC.glob("*.inc"))]   # *.inc: generated streams (tools/gen)
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     jobs = []

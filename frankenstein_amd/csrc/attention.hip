@@ -245,9 +245,43 @@ template <int N> FK_DEV void zero_acc(f32x16 (&a)[N]) {
     for (int r = 0; r < 16; ++r) a[i][r] = 0.0f;
 }
 
-// store a [d x q] accumulator set (lane = q row, registers = d) as rows of a [.., H, D] matrix
+// store a [d x q] accumulator set (lane = q row, registers = d) as rows of a [.., H, D] matrix.
+// bf16: a lane holds 4 consecutive d (8 bytes) per register group g, its partner lane (+32) the next 4.  Stored as they stand, every row
+// received 16-byte pieces, two lanes per 32-byte sector: the forward wrote 352 MB for a 156 MB output (rocprofv3 WRITE_SIZE, round 2) and
+// the store tail is issue-bound (MI355X_MICROARCH.md: "row-per-lane dwordx2 store tail").  v_permlane32_swap pairs the groups instead:
+// after swapping (g even, g odd) between the two half-waves, lane li owns d = 8g .. 8g+7 of g = 2 gp and lane li + 32 those of g = 2 gp + 1,
+// so one global_store_dwordx4 per lane writes a whole 32-byte sector per row (half the store instructions, no partial sectors).
+FK_DEV void swap_halves(unsigned& x, unsigned& y) {      // x[lanes 32-63] <-> y[lanes 0-31]
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  x = r[0];
+  y = r[1];
+}
+FK_DEV unsigned pack_bf16x2(float lo, float hi) {
+  bf16x2 v = {(bf16_t)lo, (bf16_t)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
 template <typename T, int D>
 FK_DEV void store_rows_T(T* base, int64_t rs, int row, bool row_ok, const f32x16 (&acc)[AT<T, D>::DT], float mul, int lh) {
+  if constexpr (sizeof(T) == 2 && D % 16 == 0) {
+    // every lane takes part in the swaps (EXEC must be whole for them); rows past the end only skip the store
+    T* rowp = base + (int64_t)row * rs;
+#pragma unroll
+    for (int dt = 0; dt < AT<T, D>::DT; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        if (dt * 32 + 16 * gp < D) {
+          const int g = 2 * gp;
+          unsigned x0 = pack_bf16x2(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul), x1 = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+          unsigned y0 = pack_bf16x2(acc[dt][4 * g + 4] * mul, acc[dt][4 * g + 5] * mul), y1 = pack_bf16x2(acc[dt][4 * g + 6] * mul, acc[dt][4 * g + 7] * mul);
+          swap_halves(x0, y0);
+          swap_halves(x1, y1);
+          if (row_ok) *reinterpret_cast<u32x4*>(rowp + dt * 32 + 8 * (g + lh)) = u32x4{x0, x1, y0, y1};
+        }
+      }
+    return;
+  }
   if (!row_ok) return;
 #pragma unroll
   for (int dt = 0; dt < AT<T, D>::DT; ++dt)
@@ -275,6 +309,37 @@ FK_DEV void store_rows_T(T* base, int64_t rs, int row, bool row_ok, const f32x16
 template <typename T, int D>
 FK_DEV void store_rows_T_rope(T* base, int64_t rs, int row, bool row_ok, const f32x16 (&acc)[AT<T, D>::DT], float mul, int lh,
                               const float* table) {   // table -> (cos, sin) pairs of this row: [D/2][2]
+  auto rot = [&](int dt, int g, float (&o)[4]) {
+    const int d = dt * 32 + 8 * g + 4 * lh;
+    f32x4 cs = {1.0f, 0.0f, 1.0f, 0.0f};
+    if (row_ok) cs = *reinterpret_cast<const f32x4*>(table + d);   // (c0, s0, c1, s1) for pairs d/2, d/2+1
+#ifdef FK_ROPE_EPI_NOPS
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");
+#endif
+    const float a0 = acc[dt][4 * g] * mul, a1 = acc[dt][4 * g + 1] * mul, a2 = acc[dt][4 * g + 2] * mul, a3 = acc[dt][4 * g + 3] * mul;
+    o[0] = a0 * cs[0] + a1 * cs[1];
+    o[1] = -a0 * cs[1] + a1 * cs[0];
+    o[2] = a2 * cs[2] + a3 * cs[3];
+    o[3] = -a2 * cs[3] + a3 * cs[2];
+  };
+  if constexpr (sizeof(T) == 2 && D % 16 == 0) {
+    T* rowp = base + (int64_t)row * rs;
+#pragma unroll
+    for (int dt = 0; dt < AT<T, D>::DT; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        if (dt * 32 + 16 * gp < D) {
+          float ox[4], oy[4];
+          rot(dt, 2 * gp, ox);
+          rot(dt, 2 * gp + 1, oy);
+          unsigned x0 = pack_bf16x2(ox[0], ox[1]), x1 = pack_bf16x2(ox[2], ox[3]), y0 = pack_bf16x2(oy[0], oy[1]), y1 = pack_bf16x2(oy[2], oy[3]);
+          swap_halves(x0, y0);
+          swap_halves(x1, y1);
+          if (row_ok) *reinterpret_cast<u32x4*>(rowp + dt * 32 + 8 * (2 * gp + lh)) = u32x4{x0, x1, y0, y1};
+        }
+      }
+    return;
+  }
   if (!row_ok) return;
 #pragma unroll
   for (int dt = 0; dt < AT<T, D>::DT; ++dt)
@@ -282,19 +347,14 @@ FK_DEV void store_rows_T_rope(T* base, int64_t rs, int row, bool row_ok, const f
     for (int g = 0; g < 4; ++g) {
       const int d = dt * 32 + 8 * g + 4 * lh;
       if (d < D) {
-        const f32x4 cs = *reinterpret_cast<const f32x4*>(table + d);   // (c0, s0, c1, s1) for pairs d/2, d/2+1
-#ifdef FK_ROPE_EPI_NOPS
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");
-#endif
-        const float a0 = acc[dt][4 * g] * mul, a1 = acc[dt][4 * g + 1] * mul, a2 = acc[dt][4 * g + 2] * mul, a3 = acc[dt][4 * g + 3] * mul;
-        const float o0 = a0 * cs[0] + a1 * cs[1], o1 = -a0 * cs[1] + a1 * cs[0];
-        const float o2 = a2 * cs[2] + a3 * cs[3], o3 = -a2 * cs[3] + a3 * cs[2];
+        float o[4];
+        rot(dt, g, o);
         T* dst = base + (int64_t)row * rs + d;
         if constexpr (sizeof(T) == 2) {
-          bf16x4 v = {(bf16_t)o0, (bf16_t)o1, (bf16_t)o2, (bf16_t)o3};
+          bf16x4 v = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
           *reinterpret_cast<bf16x4*>(dst) = v;
         } else {
-          *reinterpret_cast<f32x4*>(dst) = f32x4{o0, o1, o2, o3};
+          *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
         }
       }
     }
@@ -660,7 +720,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
     if (t + 1 < ntiles) tile_step(std::integral_constant<int, 1>{}, t + 1);
   }
   T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
-  if (p.rope_table && q_ok)
+  if (p.rope_table)           // wave-uniform: the stores swap registers between the half-waves, every lane takes part
     store_rows_T_rope<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + qrow) * D);
   else
     store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
@@ -866,7 +926,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   }
   T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
   T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
-  if (p.rope_table && k_ok)
+  if (p.rope_table)           // wave-uniform: the stores swap registers between the half-waves, every lane takes part
     store_rows_T_rope<T, D>(dKp, p.k_rs, krow, k_ok, dk, p.scale, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + krow) * D);
   else
     store_rows_T<T, D>(dKp, p.k_rs, krow, k_ok, dk, p.scale, lh);
@@ -1263,7 +1323,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) 
     if (t + 2 < ntiles) tile_step(std::integral_constant<int, 2>{}, t + 2);
   }
   T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
-  if (p.rope_table && q_ok)
+  if (p.rope_table)           // wave-uniform: the stores swap registers between the half-waves, every lane takes part
     store_rows_T_rope<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + qrow) * D);
   else
     store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
@@ -1837,7 +1897,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
   // dK = scale * dS^T Q = ln(2) * dS^T Q'   (Q' = scale * log2(e) * Q)
   T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
   T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
-  if (p.rope_table && k_ok)
+  if (p.rope_table)           // wave-uniform: the stores swap registers between the half-waves, every lane takes part
     store_rows_T_rope<T, D>(dKp, p.k_rs, krow, k_ok, dk, LN2, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + krow) * D);
   else
     store_rows_T<T, D>(dKp, p.k_rs, krow, k_ok, dk, LN2, lh);

@@ -682,73 +682,60 @@ def cross_entropy(logits: Tensor, targets: Tensor, ignore_index: int = -100) -> 
 
 
 class HeadCrossEntropy(torch.autograd.Function):
-    """loss = mean CE(Linear([LN](x)), targets) over the rows whose target != ignore_index, WITHOUT a [rows, V] tensor: the head GEMM runs
-    over the vocabulary in chunks, each fp32 chunk is folded into per-row running (max, sum exp, target logit) statistics
-    (fk_ce_chunk_fwd) and dropped; the backward recomputes each chunk, turns it into its d-logits (fk_ce_chunk_bwd, compute dtype) and
-    feeds the dgrad / wgrad GEMMs chunk by chunk.  lm_head + F.cross_entropy of models/gpt2_model.py:205-210 and the `to_words` head of
-    the notebook CE BrainFormer; used when the caller does not need the logits (`fuse_head_loss`).  Peak extra memory
-    rows x chunk instead of 2 x rows x V; one extra head GEMM (the recompute)."""
+    """loss = mean CE(Linear([LN](x)), targets) over the rows whose target != ignore_index, WITHOUT a [rows, V] tensor in either
+    direction: lm_head + F.cross_entropy of models/gpt2_model.py:205-210 and the `to_words` head of the notebook CE BrainFormer, used when
+    the caller does not need the logits (`fuse_head_loss`).
+    forward : ONE product — fk_head_ce_fwd keeps every 128 x 128 logits tile in the MFMA accumulators and emits per-row (max, sum exp,
+              target logit); fk_ce_chunk_finish turns them into the row log-sum-exp and the loss.
+    backward: the product again with the vocabulary on the lane, its epilogue writing the TRANSPOSED d-logits dlT [V, rows] (bf16 in the
+              throughput mode: 80 MB at rows = 800, V = 50257), so that dH = dlT^T W is a contraction over the vocabulary (fk_gemm_tn, split
+              slabs) and dW = dlT H (fk_gemm_nt over the rows) — no GEMM with K = 50257 and 21 workgroups.
+    Targets outside [0, V) other than ignore_index contribute nothing to the loss' numerator but count as valid rows in neither
+    (F.cross_entropy would raise): callers pass token ids.  `chunk` is accepted for compatibility and unused."""
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w, b, targets, eps, ignore_index, chunk):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        rows, V = x2.shape[0], w.shape[0]
+        V = w.shape[0]
         has_ln = ln_w is not None
         if has_ln:
             h, mean, rstd = K.norm_fwd(x2, ln_w.detach(), None if ln_b is None else ln_b.detach(), eps)
         else:
-            h, mean, rstd = x2, None, None
+            h, mean, rstd = to_compute(x2), None, None
         vec = 8 if h.dtype == torch.bfloat16 else 4
         npad = (V + vec - 1) // vec * vec
-        chunk = max(vec, chunk // vec * vec)
         wsh = shadow([w], pad_n=npad)
-        bpad = None
-        if b is not None:
-            bpad = torch.zeros(npad, dtype=h.dtype, device=h.device)
-            K.copy2d(shadow([b]).view(1, V), bpad[:V].view(1, V))
+        bsh = None if b is None else shadow([b])
         tg = targets.reshape(-1).contiguous()
-        st = K.CeChunkState(rows, h.device)
-        for c0 in range(0, npad, chunk):
-            c1 = min(npad, c0 + chunk)
-            lg = K.gemm_nt(h, wsh[c0:c1], bias=None if bpad is None else bpad[c0:c1], out_dtype=torch.float32)
-            K.ce_chunk_fwd(lg[:, :min(V, c1) - c0], tg, c0, st)
-        loss2, lse = K.ce_chunk_finish(st, tg, V, ignore_index)
-        ctx.cfg = (has_ln, ln_b is not None, b is not None, ignore_index, chunk, npad, vec)
-        ctx.ln_b, ctx.bpad = ln_b, bpad
-        ctx.save_for_backward(x, ln_w, w, h if has_ln else None, mean, rstd, tg, lse, loss2)
+        loss2, lse = K.head_ce_fwd(h, wsh, bsh, tg, V, ignore_index)
+        ctx.cfg = (has_ln, b is not None, ignore_index, npad)
+        ctx.ln_b = ln_b
+        ctx.save_for_backward(x, ln_w, w, b, h, mean, rstd, tg, lse, loss2)
         return loss2[0]
 
     @staticmethod
     def backward(ctx, gout):
-        x, ln_w, w, h, mean, rstd, tg, lse, loss2 = ctx.saved_tensors
-        has_ln, has_lnb, has_b, ignore_index, chunk, npad, vec = ctx.cfg
+        x, ln_w, w, b, h, mean, rstd, tg, lse, loss2 = ctx.saved_tensors
+        has_ln, has_b, ignore_index, npad = ctx.cfg
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        if h is None:
-            h = x2
         rows, d, V = h.shape[0], h.shape[1], w.shape[0]
         g = gout.reshape(1).float().contiguous()
-        wsh, wT = shadow([w], pad_n=npad), shadow([w], transpose=True, pad_n=npad)
-        dh32 = None
-        dwp = torch.empty((npad, d), dtype=torch.float32, device=h.device)
-        db = torch.empty(npad, dtype=torch.float32, device=h.device) if has_b else None
-        for c0 in range(0, npad, chunk):
-            c1 = min(npad, c0 + chunk)
-            lg = K.gemm_nt(h, wsh[c0:c1], bias=None if ctx.bpad is None else ctx.bpad[c0:c1], out_dtype=torch.float32)
-            dl = torch.empty((rows, c1 - c0), dtype=h.dtype, device=h.device)
-            K.ce_chunk_bwd(lg, tg, c0, min(V, c1) - c0, lse, loss2, g, dl, V, ignore_index)
-            part = K.gemm_nt(dl, wT[:, c0:c1], out_dtype=torch.float32)           # [rows, d] += dl_chunk @ W_chunk
-            dh32 = part if dh32 is None else K.add(dh32, part)
-            K.gemm_tn(dl, h, out=dwp[c0:c1])                                      # dW rows of this chunk
-            if has_b:
-                K.colsum(dl, out=db[c0:c1])
-        dh = dh32 if h.dtype == torch.float32 else K.cast(dh32, h.dtype)
+        wsh = shadow([w], pad_n=npad)
+        bsh = shadow([b]) if has_b else None
+        rows_pad = (rows + 63) // 64 * 64                                   # K of the weight-gradient product: whole 64-element k-tiles
+        dlT, db = K.head_ce_bwd(h, wsh, bsh, tg, lse, loss2, g, V, npad, rows_pad, has_b, ignore_index)
+        dh32 = K.gemm_tn(dlT, wsh)                                          # [rows_pad, d] = sum_v dlT[v, m] W[v, :]
+        dh = dh32[:rows] if h.dtype == torch.float32 else K.cast(dh32[:rows], h.dtype)
+        hT = torch.zeros((d, rows_pad), dtype=h.dtype, device=h.device)
+        K.transpose2d(h, out=hT)
+        dw = K.gemm_nt(dlT, hT, out_dtype=torch.float32)[:V]                # [V, d] = sum_m dlT[v, m] H[m, :]
         if has_ln:
             dx, dg, dbe = norm_bwd(dh, x2, ln_w, ctx.ln_b, mean, rstd)
         else:
-            dx, dg, dbe = dh, None, None
-        return dx.view(shp), dg, dbe, dwp[:V], (db[:V] if has_b else None), None, None, None, None
+            dx, dg, dbe = (dh if dh.dtype == x2.dtype else K.cast(dh, x2.dtype)), None, None
+        return dx.view(shp), dg, dbe, dw, db, None, None, None, None
 
 
 def head_cross_entropy(x: Tensor, ln_w, ln_b, w: Tensor, b, targets: Tensor, eps: float = 1e-5, ignore_index: int = -100,

@@ -618,6 +618,47 @@ def ce_chunk_bwd(logits: Tensor, targets: Tensor, col0: int, cw_valid: int, lse:
     return dl
 
 
+def head_ce_fwd(h: Tensor, w: Tensor, bias: Optional[Tensor], targets: Tensor, V: int, ignore_index: int = -100):
+    """(loss2, row_lse) of mean CE(h @ w[:V]^T (+ bias), targets) without the [rows, V] logits (fk_head_ce_fwd + fk_ce_chunk_finish)."""
+    assert h.dim() == 2 and w.dim() == 2 and h.shape[1] == w.shape[1] and h.dtype == w.dtype and h.stride(1) == 1 and w.stride(1) == 1
+    assert w.shape[0] >= V and targets.dtype == torch.int64 and targets.is_contiguous() and targets.numel() == h.shape[0]
+    rows, Kd = h.shape
+    if bias is not None:
+        assert bias.dtype == h.dtype and bias.is_contiguous() and bias.numel() >= V
+    st = CeChunkState(rows, h.device)
+    ws, nb = _ws(lib().fk_head_ce_workspace_bytes(rows, V), h.device)
+    with _timed(f"head_ce_fwd:{rows}x{V}x{Kd}"):
+        call("fk_head_ce_fwd", h.data_ptr(), h.stride(0), w.data_ptr(), w.stride(0), w.shape[0], _ptr(bias), targets.data_ptr(),
+             st.m.data_ptr(), st.s.data_ptr(), st.t.data_ptr(), rows, V, Kd, fk_dtype(h), _ptr(ws), nb, _stream())
+    st.first = False
+    return ce_chunk_finish(st, targets, V, ignore_index)
+
+
+def head_ce_bwd(h: Tensor, w: Tensor, bias: Optional[Tensor], targets: Tensor, lse: Tensor, loss2: Tensor, gout: Tensor, V: int,
+                vpad: int, rows_pad: int, want_bias: bool, ignore_index: int = -100):
+    """dlT [vpad, rows_pad] (transposed d-logits, zero padded) and, for a head with bias, its gradient [V] (fk_head_ce_bwd)."""
+    rows, Kd = h.shape
+    dlT = torch.empty((vpad, rows_pad), dtype=h.dtype, device=h.device)
+    dbpart = torch.empty((2 * ((rows + 127) // 128), vpad), dtype=torch.float32, device=h.device) if want_bias else None
+    with _timed(f"head_ce_bwd:{rows}x{V}x{Kd}"):
+        call("fk_head_ce_bwd", h.data_ptr(), h.stride(0), w.data_ptr(), w.stride(0), w.shape[0], _ptr(bias), targets.data_ptr(),
+             lse.data_ptr(), loss2.data_ptr(), gout.data_ptr(), dlT.data_ptr(), dlT.stride(0), rows_pad, vpad, _ptr(dbpart), rows, V, Kd,
+             ignore_index, fk_dtype(h), _stream())
+    db = colsum(dbpart)[:V] if want_bias else None
+    return dlT, db
+
+
+def transpose2d(src: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """out[c, r] = src[r, c]; a given `out` may be larger (its padding is left as it is)."""
+    assert src.dim() == 2 and src.stride(1) == 1
+    rows, cols = src.shape
+    if out is None:
+        out = torch.empty((cols, rows), dtype=src.dtype, device=src.device)
+    assert out.dtype == src.dtype and out.stride(1) == 1 and out.shape[0] >= cols and out.shape[1] >= rows
+    call("fk_transpose2d", src.data_ptr(), src.stride(0), out.data_ptr(), out.stride(0), rows, cols, fk_dtype(src), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------- GPT embedding
 def gpt_embed_fwd(idx: Tensor, prefix: Optional[Tensor], wte: Tensor, wpe: Tensor, dtype: torch.dtype) -> Tensor:
     B, t_words = idx.shape

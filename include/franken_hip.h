@@ -252,6 +252,27 @@ int fk_ce_chunk_bwd(const float* logits, int64_t ld, const int64_t* targets, int
                     const float* grad_out, void* dlogits, int64_t ldd, int64_t rows, int64_t cw, int64_t cw_valid, int64_t V,
                     int64_t ignore_index, int dtype, void* stream);
 
+/* ---- vocabulary head + cross entropy as one product each way (csrc/head_ce.hip): lm_head + F.cross_entropy of models/gpt2_model.py:205-210
+ *      and the `to_words` head of the notebook CE BrainFormer (notebooks_trainer/train_brainformer.ipynb cell 3) when only the loss is
+ *      needed (utils/train_utils.py:138-139).  No [rows, V] tensor in either direction.
+ *   fk_head_ce_fwd : row_m / row_s / row_t (running maximum, sum of exponentials, target logit; the inputs of fk_ce_chunk_finish) of
+ *                    logits = H W^T (+ bias) straight from the MFMA accumulators.  H [rows, K] (ldh), W [wrows >= V, K] (ldw, rows past V
+ *                    unused), bias [>= V] or NULL in the compute dtype, targets int64 [rows].  workspace: fk_head_ce_workspace_bytes.
+ *   fk_head_ce_bwd : dlT [vpad, rows_pad] (row stride lddl) = TRANSPOSED d-logits, (exp(logit - row_lse) - onehot) * grad_out[0] / loss2[1]
+ *                    on rows whose target != ignore_index and vocabulary entries < V, zero elsewhere (the padding feeds GEMMs):
+ *                    dH = fk_gemm_tn(dlT, W), dW = fk_gemm_nt(dlT, H^T).  dbpart (nullable): [2 * ceil(rows / 128), vpad] partial column
+ *                    sums of the d-logits (bias gradient = their column sum).  rows <= rows_pad <= ceil(rows/128)*128, rows_pad % 4 == 0,
+ *                    V <= vpad <= ceil(V/128)*128.
+ *   fk_transpose2d : dst[c, r] = src[r, c] (H^T for the product above). */
+size_t fk_head_ce_workspace_bytes(int64_t rows, int64_t V);
+int fk_head_ce_fwd(const void* H, int64_t ldh, const void* W, int64_t ldw, int64_t wrows, const void* bias, const int64_t* targets,
+                   float* row_m, float* row_s, float* row_t, int64_t rows, int64_t V, int64_t K, int dtype, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int fk_head_ce_bwd(const void* H, int64_t ldh, const void* W, int64_t ldw, int64_t wrows, const void* bias, const int64_t* targets,
+                   const float* row_lse, const float* loss2, const float* grad_out, void* dlT, int64_t lddl, int64_t rows_pad,
+                   int64_t vpad, float* dbpart, int64_t rows, int64_t V, int64_t K, int64_t ignore_index, int dtype, void* stream);
+int fk_transpose2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, int dtype, void* stream);
+
 /* ---- optimizer: torch.optim.AdamW step fused with clip_grad_value_ (utils/train_utils.py:117-119,142-143) over a
  *      flat fp32 arena: g' = clamp(g * grad_scale, -clip, clip) (clip <= 0: no clamp); p *= 1 - lr*wd;
  *      m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).

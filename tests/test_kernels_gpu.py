@@ -786,3 +786,54 @@ def test_sample_topk_on_device(K):
     for _ in range(6):
         K.sample_topk(lg, T, k, st4, cur=cur, out=small)
     assert int(st4.step) == 6 and bool((buf[:, 3:] == -7).all()) and bool((buf[:, :3] >= 0).all())
+
+
+# ----------------------------------------------------------------------------------------------- fused head + cross entropy
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,V,Kd,bias", [(203, 211, 64, True), (130, 1000, 96, False), (64, 129, 32, True)])
+def test_head_ce_fused_kernels(K, dtype, rows, V, Kd, bias):
+    """fk_head_ce_fwd / fk_head_ce_bwd (lm_head + F.cross_entropy, models/gpt2_model.py:205-210, without the logits) against torch on the
+    same rounded operands: loss, row log-sum-exp, the transposed d-logits (padding rows / columns zero) and the bias gradient; ragged
+    rows / V (last tiles partly or, for a wave, wholly past V), ignored rows, fk_transpose2d."""
+    vec = 8 if dtype == torch.bfloat16 else 4
+    npad = (V + vec - 1) // vec * vec
+    h = q(rnd(rows, Kd, seed=1), dtype)
+    w = q(rnd(V, Kd, seed=2, scale=0.5), dtype)
+    b = q(rnd(V, seed=3), dtype) if bias else None
+    tg = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(4))
+    tg[::7] = -100
+    tg[5] = V - 1
+    tg[6] = 0
+    wpad = torch.zeros(npad, Kd)
+    wpad[:V] = w
+    hd, wd = dev(h, dtype), dev(wpad, dtype)
+    bd = None if b is None else dev(b, dtype)
+    tgd = tg.cuda()
+    loss2, lse = K.head_ce_fwd(hd, wd, bd, tgd, V)
+    hr = h.clone().requires_grad_(True)
+    logits = hr @ w.t() + (b if b is not None else 0.0)
+    want = torch.nn.functional.cross_entropy(logits, tg, ignore_index=-100)
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert abs(float(loss2[0]) - float(want)) < tol * max(1.0, abs(float(want))) and int(loss2[1]) == int((tg != -100).sum())
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(logits.detach(), -1), atol=tol * 5, rtol=tol)
+    gout = torch.tensor([0.7], device="cuda")
+    rows_pad = (rows + 63) // 64 * 64
+    dlT, db = K.head_ce_bwd(hd, wd, bd, tgd, lse, loss2, gout, V, npad, rows_pad, bias)
+    logits.retain_grad()
+    (want * 0.7).backward()
+    full = torch.zeros(npad, rows_pad)
+    full[:V, :rows] = logits.grad.t()
+    close(dlT, full, dtype, atol32=1e-6, rtol32=1e-4, atol16=2e-5, rtol16=2e-2)
+    assert float(dlT[V:].abs().max()) == 0.0 if npad > V else True
+    assert float(dlT[:, rows:].abs().max()) == 0.0 if rows_pad > rows else True
+    if bias:
+        torch.testing.assert_close(db.cpu(), logits.grad.sum(0), atol=2e-5 if dtype == torch.float32 else 2e-4, rtol=1e-2)
+    # the two gradient products as engine.HeadCrossEntropy forms them
+    dh = K.gemm_tn(dlT, wd)[:rows]
+    close(dh, hr.grad, dtype, atol32=1e-5, rtol32=1e-4, atol16=2e-3 * float(hr.grad.abs().max()) + 1e-6, rtol16=3e-2)
+    hT = torch.zeros((Kd, rows_pad), dtype=dtype, device="cuda")
+    K.transpose2d(hd, out=hT)
+    assert torch.equal(hT[:, :rows].t().contiguous(), hd) and float(hT[:, rows:].abs().max() if rows_pad > rows else 0.0) == 0.0
+    dw = K.gemm_nt(dlT, hT, out_dtype=torch.float32)[:V]
+    want_dw = logits.grad.t() @ h
+    close(dw, want_dw, dtype, atol32=1e-5, rtol32=1e-4, atol16=2e-3 * float(want_dw.abs().max()) + 1e-6, rtol16=3e-2)
