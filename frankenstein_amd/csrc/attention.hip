@@ -2010,6 +2010,107 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_asm_kernel(AttnArgs p) {
 }
 #endif
 
+#ifndef FK_NO_DKDVW_ASM
+#include "attn_dkdvw_asm.inc"     // generated by tools/gen/gen_dkdvw_asm.py: the tile step of the wide dK/dV kernel
+// ------------------------------------------------------------------------------------------------- dK, dV: 64 keys per wave, one wave per SIMD
+// Same algorithm, ring and requests as attn_bwd_dkdv_asm_kernel; a wave owns 64 keys (two 32-key blocks), a workgroup 256, so every LDS
+// fragment of the Q / dO tile feeds two MFMAs (1.25 LDS reads per MFMA instead of 2) and a tile fetch serves twice the keys.  The 128
+// accumulator registers (dK, dV of both key blocks) and the 64 K / V fragment registers are "a" operands of the stream: they live in the
+// accumulator half of the 512-register file, the stream's temporaries (v40-v231) and the compiler's values in the other half.
+// Launched when the fully-visible / aligned conditions of the narrow stream hold for 256-key workgroups (Nk % 256 == 0, mask block % 256 == 0).
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdvw_asm_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64, TQ = 64, BK = 256, IMG = TQ * 128, NS = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkb = p.Nk / BK;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = (int)(L / nkb), b = bh / p.H, hd = bh % p.H, k0 = (int)(L % nkb) * BK;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const int krow0 = k0 + wave * 64 + li;                 // key block kb: krow0 + 32 kb
+  const int qs = q_first(p, b, k0);                      // a multiple of the mask block, hence of TQ
+  const int ntiles = (p.Nq - qs) / TQ;
+  const int nqp = p.Nq;
+  const float* nl_g = p.delta + ((int64_t)b * p.H + hd) * nqp;
+  const float* nd_g = nl_g + (int64_t)p.B * p.H * nqp;
+  unsigned vo[5];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+    const int g = (row >> 1) & 7, f = g ^ ((g & 1) << 2);
+    vo[j] = (__umul24((unsigned)row, (unsigned)p.q_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+    vo[2 + j] = (__umul24((unsigned)row, (unsigned)p.o_rs) + (unsigned)(((lane & 7) ^ f) * 8)) * 2u;
+  }
+  vo[4] = (unsigned)lane * 4u;
+  const float* st_g = (wave & 1) ? nd_g : nl_g;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 2048u);
+  const unsigned ldss = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * NS * IMG) + (unsigned)(wave & 1) * 256u);
+  auto tile_row = [&](int tt) { return qs + (tt < ntiles ? tt : ntiles - 1) * TQ; };
+  auto q_base = [&](int tt) { return (uint64_t)(uintptr_t)(Qp + (int64_t)tile_row(tt) * p.q_rs); };
+  auto g_base = [&](int tt) { return (uint64_t)(uintptr_t)(Gp + (int64_t)tile_row(tt) * p.o_rs); };
+  auto s_base = [&](int tt) { return (uint64_t)(uintptr_t)(st_g + tile_row(tt)); };
+  if (ntiles > 0) {
+    dkdv_request_asm_slot0(vo, q_base(0), g_base(0), s_base(0), ldsw, ldss);
+    dkdv_request_asm_slot1(vo, q_base(1), g_base(1), s_base(1), ldsw, ldss);
+  }
+  bf16x8 kfv[2][4], vfv[2][4];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kfv[kb][s] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)(krow0 + 32 * kb) * p.k_rs + 16 * s + 8 * lh);
+      vfv[kb][s] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)(krow0 + 32 * kb) * p.v_rs + 16 * s + 8 * lh);
+    }
+  f32x16 dk[2][2], dv[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) { zero_acc(dk[kb]); zero_acc(dv[kb]); }
+  unsigned aq[4], va0, va1;
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) aq[s_] = lds0 + (unsigned)Img<T, D>::off(li, (16 * s_ + 8 * lh) * 2);
+  {
+    const int g4 = lane >> 4, i16 = lane & 15, hh = g4 >> 1;
+    const int rpart = (4 * hh + (i16 >> 2)) * 128 + (i16 & 1) * 8;
+    const int c0 = 2 * (g4 & 1) + ((i16 & 3) >> 1), gg0 = 2 * hh + (i16 >> 3), f0 = gg0 ^ ((gg0 & 1) << 2);
+    va0 = lds0 + (unsigned)(rpart + ((c0 ^ f0) << 4));
+    va1 = lds0 + (unsigned)(rpart + (((c0 ^ f0) ^ 4) << 4));
+  }
+  const unsigned ast = lds0 + (unsigned)(2 * NS * IMG) + (unsigned)lh * 16u;
+  if (ntiles > 0) {
+    asm volatile("" ::"a"(kfv[0][0]), "a"(kfv[0][1]), "a"(kfv[0][2]), "a"(kfv[0][3]), "a"(vfv[0][0]), "a"(vfv[0][1]), "a"(vfv[0][2]), "a"(vfv[0][3]),
+                 "a"(kfv[1][0]), "a"(kfv[1][1]), "a"(kfv[1][2]), "a"(kfv[1][3]), "a"(vfv[1][0]), "a"(vfv[1][1]), "a"(vfv[1][2]), "a"(vfv[1][3]));
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // The steps are software pipelined: a step finds half 0's statistics and row fragments of ITS tile in the carried registers (read by the
+    // previous step behind its barrier; by dkdvw_prefetch_asm for tile 0) and starts with its MFMAs; the wait for tile t + 1 and the
+    // barrier sit inside the step, the requests of tile t + 2 behind them.
+    f32x16 c0, c1, c2, c3, c4, c5;
+    dkdvw_prefetch_asm(c0, c1, c2, c3, c4, c5, aq, ast);
+    for (int t = 0; t < ntiles; t += 3) {
+      dkdvw_tile_asm_slot0(dk, dv, kfv, vfv, c0, c1, c2, c3, c4, c5, aq, va0, va1, ast, vo, q_base(t + 2), g_base(t + 2), s_base(t + 2), ldsw, ldss);
+      if (t + 1 < ntiles) dkdvw_tile_asm_slot1(dk, dv, kfv, vfv, c0, c1, c2, c3, c4, c5, aq, va0, va1, ast, vo, q_base(t + 3), g_base(t + 3), s_base(t + 3), ldsw, ldss);
+      if (t + 2 < ntiles) dkdvw_tile_asm_slot2(dk, dv, kfv, vfv, c0, c1, c2, c3, c4, c5, aq, va0, va1, ast, vo, q_base(t + 4), g_base(t + 4), s_base(t + 4), ldsw, ldss);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (unused) requests past the last tile have landed before the workgroup ends
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the stream's last MFMAs have retired before the compiler reads the accumulators
+  T* dKp = (T*)p.dK + (int64_t)b * p.k_bs + hd * D;
+  T* dVp = (T*)p.dV + (int64_t)b * p.v_bs + hd * D;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int krow = krow0 + 32 * kb;
+    if (p.rope_table)
+      store_rows_T_rope<T, D>(dKp, p.k_rs, krow, true, dk[kb], LN2, lh, p.rope_table + (int64_t)b * p.rope_bs + (int64_t)(p.rope_off + krow) * D);
+    else
+      store_rows_T<T, D>(dKp, p.k_rs, krow, true, dk[kb], LN2, lh);
+    store_rows_T<T, D>(dVp, p.v_rs, krow, true, dv[kb], 1.0f, lh);
+  }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------- host
 template <typename T, int D> size_t fwd_lds() {
   return Img<T, D>::SWZ ? (size_t)3 * 2 * BKV * 128 : (size_t)2 * BKV * (AT<T, D>::RSTRIDE + AT<T, D>::VSTRIDE);
@@ -2090,6 +2191,15 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
         allow_lds(attn_bwd_dq_ps_kernel<NWQ>, DQ_PS_LDS);
         hipLaunchKernelGGL(attn_bwd_dq_ps_kernel<NWQ>, gq2, dim3(NWQ * 64), DQ_PS_LDS, s, a);
       }
+#ifndef FK_NO_DKDVW_ASM
+      static const bool no_wide = getenv("FK_ATTN_NO_DKDVW") != nullptr;    // tuning knob: the 32-keys-per-wave stream instead
+      const bool vis_256 = a.q_off == 0 && a.k_off == 0 && (a.mask_kind == FK_MASK_NONE || (a.mask_kind == FK_MASK_BLOCK_CAUSAL && a.mask_c % 256 == 0));
+      if (!no_wide && vis_256 && a.Nk % 256 == 0 && a.Nq % 64 == 0) {
+        allow_lds(attn_bwd_dkdvw_asm_kernel, DKDV_PS_LDS);
+        hipLaunchKernelGGL(attn_bwd_dkdvw_asm_kernel, dim3((unsigned)(a.Nk / 256 * a.H * a.B)), dim3(256), DKDV_PS_LDS, s, a);
+        return 0;
+      }
+#endif
 #ifndef FK_NO_DKDV_ASM
       if (vis_all && a.Nk % 128 == 0 && a.Nq % 64 == 0) {
         allow_lds(attn_bwd_dkdv_asm_kernel, DKDV_PS_LDS);

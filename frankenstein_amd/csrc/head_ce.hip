@@ -182,21 +182,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void head_ce_kernel(HeadCeArgs p) {
   }
 }
 
-// row_m / row_s of a row = its npart (max, sum exp) pairs merged in index order: deterministic
-__global__ void head_ce_merge_kernel(const float* pmax, const float* psum, float* row_m, float* row_s, int rows, int npart) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= rows) return;
+// row_m / row_s of a row = its npart (max, sum exp) pairs merged by one wave (coalesced reads, a fixed summation tree: deterministic)
+__global__ __launch_bounds__(64) void head_ce_merge_kernel(const float* pmax, const float* psum, float* row_m, float* row_s, int rows, int npart) {
+  const int row = blockIdx.x, lane = threadIdx.x;
   const float* pm = pmax + (int64_t)row * npart;
   const float* ps = psum + (int64_t)row * npart;
   float M = -INFINITY;
-  for (int i = 0; i < npart; ++i) M = fmaxf(M, pm[i]);
+  for (int i = lane; i < npart; i += 64) M = fmaxf(M, pm[i]);
+  M = wave_max(M);
   float S = 0.0f;
-  for (int i = 0; i < npart; ++i) {
+  for (int i = lane; i < npart; i += 64) {
     const float m = pm[i];
     if (m != -INFINITY) S += ps[i] * __expf(m - M);
   }
-  row_m[row] = M;
-  row_s[row] = S;
+  S = wave_sum(S);
+  if (lane == 0) {
+    row_m[row] = M;
+    row_s[row] = S;
+  }
 }
 
 template <typename T>
@@ -237,7 +240,7 @@ int fk_head_ce_fwd(const void* H, int64_t ldh, const void* W, int64_t ldw, int64
   if (dtype == FK_BF16) hipLaunchKernelGGL((head_ce_kernel<bf16_t, 0>), grid, block, 4 * TILE_BYTES, s, p);
   else hipLaunchKernelGGL((head_ce_kernel<float, 0>), grid, block, 4 * TILE_BYTES, s, p);
   FK_CHECK_LAUNCH("fk_head_ce_fwd");
-  hipLaunchKernelGGL(head_ce_merge_kernel, dim3((unsigned)fk_cdiv(rows, 64)), dim3(64), 0, s, (const float*)p.pmax, (const float*)p.psum, row_m, row_s, (int)rows, p.npart);
+  hipLaunchKernelGGL(head_ce_merge_kernel, dim3((unsigned)rows), dim3(64), 0, s, (const float*)p.pmax, (const float*)p.psum, row_m, row_s, (int)rows, p.npart);
   FK_CHECK_LAUNCH("fk_head_ce_fwd(merge)");
   return FK_OK;
 }

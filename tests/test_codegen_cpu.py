@@ -11,11 +11,12 @@ from tools import kernel_resources as KR
 # kernel-name fragment -> (max VGPRs, min waves/SIMD, max scratch bytes per lane, scratch instructions allowed inside ANY loop that holds MFMAs).
 # In every kernel the hot loop (the innermost loop with the most MFMAs) must be free of scratch traffic.  attn_fwd_asm_kernel is the one
 # kernel with spill traffic inside (cold) loops: the classic-softmax phase and the at most three steps that align the tile counter to the
-# four-step steady loop move the 16 carried scores through scratch (84 bytes per lane); the steady loop itself (64 MFMAs per trip) has none.
+# four-step steady loop move the 16 carried scores through scratch (88 bytes per lane; it is what the forward's WRITE_SIZE of 2.3x its output was: 36864 waves x 5.6 KB); the steady loop itself (64 MFMAs per trip) has none.
 BOUNDS = {
     "attn_bwd_dq_asm_kernel": (256, 2, 0, 0),
     "attn_bwd_dkdv_asm_kernel": (256, 2, 20, 0),
-    "attn_fwd_asm_kernel": (256, 2, 84, 40),
+    "attn_bwd_dkdvw_asm_kernel": (448, 1, 0, 0),          # one wave per SIMD by design: 245 VGPRs + 192 AGPRs (accumulators, K / V fragments)
+    "attn_fwd_asm_kernel": (256, 2, 96, 40),
     "attn_fwd_ps_kernel": (128, 4, 0, 0),
     "attn_bwd_dq_ps_kernel": (256, 2, 0, 0),
     "attn_bwd_dkdv_ps_kernel": (256, 2, 0, 0),
@@ -49,6 +50,15 @@ def test_compiled_kernel_stays_inside_its_register_and_spill_budget(table, frag)
         assert hot is None or hot[3] == 0, f"{name}: scratch traffic in the hot loop {hot}"
         if "asm_kernel" in frag:
             assert hot is not None and hot[2] >= 24, (name, hot)          # the generated tile step(s) are in that loop
+        if "dkdvw" in frag:
+            # the wide stream carries values from step to step in pinned registers and keeps accumulators / fragments in the accumulator
+            # half: no register traffic (v_mov / v_accvgpr) may appear between the steps of its loop
+            lines = open(r["_asm"]).read().splitlines()
+            start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
+            body = lines[start + hot[0]:start + hot[1]]
+            moves = [l for l in body if "v_accvgpr" in l or "v_mov_b" in l]
+            assert not moves, moves[:4]
+            assert r.get("AGPRs", 0) >= 192
 
 
 def test_lds_budgets_are_static_asserts():

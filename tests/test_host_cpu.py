@@ -329,7 +329,7 @@ def test_bench_self_launch_dry_run_world2():
         assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "AssertionError" not in r.stderr
 
 
-@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd", "dq16"])
+@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd", "dq16", "dkdvw"])
 def test_generated_streams_are_current(tmp_path, gen):
     """frankenstein_amd/csrc/attn_*_asm.inc are build inputs that are committed: the generators (tools/gen) reproduce them byte for byte."""
     import subprocess
@@ -351,7 +351,7 @@ def _verify_stream():
     return m
 
 
-@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd", "dq16"])
+@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd", "dq16", "dkdvw"])
 def test_generated_streams_keep_their_hazard_rules(gen):
     """every asm block of the committed streams replayed against the rules the generators promise (counted LDS waits, VALU -> consumer
     distance, MFMA result -> VALU distance, fragment overwrite behind its MFMA, M0 -> LDS-DMA distance): tools/gen/verify_stream.py"""

@@ -39,10 +39,12 @@ class Model:
         self.reads = self.reads[last + 1:]
 
 
-def schedule(mf, lds, va, dma_at, lds_per_gap, valu_units, tail):
+def schedule(mf, lds, va, dma_at, lds_per_gap, valu_units, tail, mid=None):
     """mf: [None, (text, [lds ids], [valu ids]), ...]; lds: id -> (text, release gap, deadline MFMA);
     va: id -> (text, cost in 4-cycle units, release gap, deadline MFMA, [producer ids]); dma_at: gap -> (set-M0 text, request text);
-    tail: instructions that end the step.  Returns the instruction list."""
+    tail: instructions that end the step; mid: gap -> instructions placed right behind that MFMA (a wait + barrier inside the step).
+    An LDS read with a deadline past the last MFMA has no consumer in this step (a prefetch for the next one): it is issued in the gaps
+    from its release on and waited for (lgkmcnt(0)) in front of the tail.  Returns the instruction list."""
     M = Model()
     lds_todo = dict(lds)
     va_todo = dict(va)
@@ -91,6 +93,9 @@ def schedule(mf, lds, va, dma_at, lds_per_gap, valu_units, tail):
                 M.lds(k, lds_todo.pop(k)[0])
         M.need(lneed)
         M.emit(text)
+        if mid and g in mid:
+            for t in mid[g]:
+                M.emit(t)
         if g == 1:
             issue_lds(1, 99, only_due=2)                        # what the second MFMA needs
         if g in dma_at:
@@ -107,6 +112,10 @@ def schedule(mf, lds, va, dma_at, lds_per_gap, valu_units, tail):
         issue_valu(99, 99)
         if len(va_todo) == before:
             M.emit("s_nop 0")
+    for k in list(lds_todo):                                    # prefetches the gaps did not fit
+        M.lds(k, lds_todo.pop(k)[0])
+    if M.reads:                                                 # reads without a consumer in this step: landed before the step ends
+        M.need(list(M.reads))
     assert not lds_todo and not va_todo and not M.reads, (lds_todo.keys(), va_todo.keys(), M.reads)
     for t in tail:
         M.emit(t)
