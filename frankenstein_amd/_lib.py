@@ -52,6 +52,7 @@ SIGNATURES = {
     "fk_scatter_add_rows": (_int, [_p, _int, _p, _i64, _p, _i64, _i64, _p]),
     "fk_prefix_mask": (_int, [_p, _p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "fk_copy2d": (_int, [_p, _i64, _p, _i64, _i64, _i64, _int, _p]),
+    "fk_attn_combine": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_add2d": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "fk_gpt_embed_step": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p]),
     "fk_kv_append": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p]),

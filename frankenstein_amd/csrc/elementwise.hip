@@ -334,6 +334,42 @@ __global__ void prefix_mask_kernel(const int64_t* qid, const int64_t* kid, int C
   }
 }
 
+// ---------------------------------------------------------------------------------------------- split-key attention: combine
+// parts [B, S, T, H, D]: S partial attention results of the same queries over S disjoint key ranges (F.scaled_dot_product_attention of
+// models/brainformer.py:215 with 32 perceiver queries against 6144 context keys: one workgroup per (batch, head) left 7 of 8 waves idle).
+// lse != null (forward): out = sum_s exp(lse[b, s, h, t] - L) parts[b, s], L = log sum_s exp(lse[b, s, h, t]) written to lse_out [B, H, T].
+// lse == null (the query gradient of the backward, whose P was normalised with the global L already): out = sum_s parts[b, s].
+template <typename T>
+__global__ void attn_combine_kernel(const T* parts, const float* lse, T* out, float* lse_out, int B, int S, int Tq, int H, int D) {
+  const int64_t total = (int64_t)B * Tq * H * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int h = (int)((i / D) % H);
+    const int t = (int)((i / ((int64_t)D * H)) % Tq);
+    const int b = (int)(i / ((int64_t)D * H * Tq));
+    const int64_t pstride = (int64_t)Tq * H * D;
+    const T* pp = parts + (int64_t)b * S * pstride + ((int64_t)t * H + h) * D + d;
+    float acc = 0.0f;
+    if (lse) {
+      const float* lp = lse + ((int64_t)b * S * H + h) * Tq + t;      // [B, S, H, T]
+      float M = -INFINITY;
+      for (int s = 0; s < S; ++s) M = fmaxf(M, lp[(int64_t)s * H * Tq]);
+      float sum = 0.0f;
+      for (int s = 0; s < S; ++s) {
+        const float l = lp[(int64_t)s * H * Tq];
+        const float w = (l == -INFINITY || M == -INFINITY || M == INFINITY) ? 0.0f : __expf(l - M);
+        sum += w;
+        acc += w * to_f32<T>(pp[(int64_t)s * pstride]);
+      }
+      acc = sum > 0.0f ? acc / sum : 0.0f;
+      if (d == 0 && lse_out) lse_out[((int64_t)b * H + h) * Tq + t] = sum > 0.0f ? M + logf(sum) : M;
+    } else {
+      for (int s = 0; s < S; ++s) acc += to_f32<T>(pp[(int64_t)s * pstride]);
+    }
+    out[i] = from_f32<T>(acc);
+  }
+}
+
 }  // namespace
 
 #define FK_DT_CHECK(name) FK_CHECK_ARG(dtype == FK_F32 || dtype == FK_BF16, name ": bad dtype %d", dtype)
@@ -469,6 +505,19 @@ int fk_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows
   if (dtype == FK_BF16) hipLaunchKernelGGL(copy2d_kernel<bf16_t>, dim3(grid_for(rows * cols, 16384)), dim3(TPB), 0, s, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, rows, cols);
   else hipLaunchKernelGGL(copy2d_kernel<float>, dim3(grid_for(rows * cols, 16384)), dim3(TPB), 0, s, (const float*)src, lds, (float*)dst, ldd, rows, cols);
   FK_CHECK_LAUNCH("fk_copy2d");
+  return FK_OK;
+}
+
+int fk_attn_combine(const void* parts, const float* lse_parts, void* out, float* lse_out, int64_t B, int64_t S, int64_t T, int64_t H,
+                    int64_t D, int dtype, void* stream) {
+  FK_DT_CHECK("fk_attn_combine");
+  FK_CHECK_ARG(parts && out && B > 0 && S > 0 && T > 0 && H > 0 && D > 0 && B * S * T * H * D < (1LL << 40) && S < 65536, "fk_attn_combine: bad arguments");
+  FK_CHECK_ARG(lse_parts || !lse_out, "fk_attn_combine: lse_out without lse_parts");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t work = B * T * H * D;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(attn_combine_kernel<bf16_t>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, (const bf16_t*)parts, lse_parts, (bf16_t*)out, lse_out, (int)B, (int)S, (int)T, (int)H, (int)D);
+  else hipLaunchKernelGGL(attn_combine_kernel<float>, dim3(grid_for(work, 16384)), dim3(TPB), 0, s, (const float*)parts, lse_parts, (float*)out, lse_out, (int)B, (int)S, (int)T, (int)H, (int)D);
+  FK_CHECK_LAUNCH("fk_attn_combine");
   return FK_OK;
 }
 

@@ -420,6 +420,31 @@ class AttnBranch(torch.autograd.Function):
         return (dx.view(B, N, d), dg, db, dpw, dpb, dqb, None, *dws)
 
 
+_ZERO_IDX: dict = {}
+
+
+def _replicate(x: Tensor, S: int) -> Tensor:
+    """x [B, ...] -> [B * S, ...] with every sample repeated S times (one gather launch; queries / outputs of split-key attention)"""
+    B = x.shape[0]
+    key = (B, S, x.device)
+    idx = _ZERO_IDX.get(key)
+    if idx is None:
+        idx = _ZERO_IDX[key] = torch.zeros((B, S), dtype=torch.int64, device=x.device)
+    return K.gather_rows(x.reshape(B, 1, -1), idx).view(B * S, *x.shape[1:])
+
+
+def _key_splits(T: int, Nc: int, mask: Mask) -> int:
+    """Split-key attention for a few queries against a long unmasked context (the perceiver's read-out): with one workgroup per
+    (sample, head) 7 of its 8 waves idle and 192 workgroups sweep 6144 keys serially; S key ranges folded into the batch dimension give
+    S times the workgroups (fk_attn_combine merges the partial results)."""
+    if mask.kind != K.MASK_NONE or T > 128 or Nc < 1024 or os.environ.get("FK_ATTN_NO_SPLIT") is not None:
+        return 1
+    for S in (8, 4, 2):
+        if Nc % (S * 128) == 0:
+            return S
+    return 1
+
+
 class CrossAttnBranch(torch.autograd.Function):
     """y = x + proj(SDPA(q = Wq LN(x), k = Wk ctx, v = Wv ctx))  (models/brainformer.py:262 with :198-219)."""
 
@@ -434,10 +459,16 @@ class CrossAttnBranch(torch.autograd.Function):
         ctx.ln_b = ln_b
         q = K.gemm_nt(h, shadow([qw]))
         kv = K.gemm_nt(c2, shadow([kw, vw]))
-        kv3 = kv.view(B, Nc, 2 * HD)
-        o, lse = K.attn_fwd(q.view(B, T, H, D), kv3[..., :HD].unflatten(-1, (H, D)), kv3[..., HD:].unflatten(-1, (H, D)), mask)
+        S = _key_splits(T, Nc, mask)
+        if S > 1:
+            kvs = kv.view(B * S, Nc // S, 2 * HD)
+            o_s, lse_s = K.attn_fwd(_replicate(q.view(B, T, H, D), S), kvs[..., :HD].unflatten(-1, (H, D)), kvs[..., HD:].unflatten(-1, (H, D)), mask)
+            o, lse = K.attn_combine(o_s.view(B, S, T, H, D), lse_s.view(B, S, H, T))
+        else:
+            kv3 = kv.view(B, Nc, 2 * HD)
+            o, lse = K.attn_fwd(q.view(B, T, H, D), kv3[..., :HD].unflatten(-1, (H, D)), kv3[..., HD:].unflatten(-1, (H, D)), mask)
         y = K.gemm_nt(o.view(B * T, HD), shadow([pw]), residual=x2)
-        ctx.spec = spec
+        ctx.spec, ctx.S = spec, S
         ctx.save_for_backward(x, context, ln_w, qw, kw, vw, pw, h, mean, rstd, q, kv, o, lse)
         return y.view(B, T, d)
 
@@ -446,17 +477,27 @@ class CrossAttnBranch(torch.autograd.Function):
         H, D, mask, eps = ctx.spec
         x, context, ln_w, qw, kw, vw, pw, h, mean, rstd, q, kv, o, lse = ctx.saved_tensors
         B, T, d = x.shape
-        Nc, HD = context.shape[1], H * D
+        Nc, HD, S = context.shape[1], H * D, ctx.S
         x2, c2 = x.view(B * T, d), context.view(B * Nc, d)
         dy2 = dy.contiguous().view(B * T, d)
         do = K.gemm_nt(dy2, shadow([pw], transpose=True))
         (dpw,) = wgrad(dy2, o.view(B * T, HD), [pw])
-        dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
-        kv3, dkv3 = kv.view(B, Nc, 2 * HD), dkv.view(B, Nc, 2 * HD)
-        K.attn_bwd(q.view(B, T, H, D), kv3[..., :HD].unflatten(-1, (H, D)), kv3[..., HD:].unflatten(-1, (H, D)), o,
-                   do.view(B, T, H, D), lse, dq.view(B, T, H, D), dkv3[..., :HD].unflatten(-1, (H, D)),
-                   dkv3[..., HD:].unflatten(-1, (H, D)), mask)
+        if S > 1:
+            # the same key ranges as the forward, every range against the replicated queries / outputs and the GLOBAL row statistics: dK / dV
+            # land in their rows of dkv, the S partial query gradients are summed by fk_attn_combine
+            kvs, dkvs = kv.view(B * S, Nc // S, 2 * HD), dkv.view(B * S, Nc // S, 2 * HD)
+            dq_s = torch.empty((B * S, T, H, D), dtype=q.dtype, device=q.device)
+            K.attn_bwd(_replicate(q.view(B, T, H, D), S), kvs[..., :HD].unflatten(-1, (H, D)), kvs[..., HD:].unflatten(-1, (H, D)),
+                       _replicate(o, S), _replicate(do.view(B, T, H, D), S), _replicate(lse, S), dq_s,
+                       dkvs[..., :HD].unflatten(-1, (H, D)), dkvs[..., HD:].unflatten(-1, (H, D)), mask)
+            dq = K.attn_combine(dq_s.view(B, S, T, H, D))[0].view(B * T, HD)
+        else:
+            dq = torch.empty_like(q)
+            kv3, dkv3 = kv.view(B, Nc, 2 * HD), dkv.view(B, Nc, 2 * HD)
+            K.attn_bwd(q.view(B, T, H, D), kv3[..., :HD].unflatten(-1, (H, D)), kv3[..., HD:].unflatten(-1, (H, D)), o,
+                       do.view(B, T, H, D), lse, dq.view(B, T, H, D), dkv3[..., :HD].unflatten(-1, (H, D)),
+                       dkv3[..., HD:].unflatten(-1, (H, D)), mask)
         dh = K.gemm_nt(dq, shadow([qw], transpose=True))
         (dqw,) = wgrad(dq, h, [qw])
         dctx = K.gemm_nt(dkv, shadow([kw, vw], transpose=True))

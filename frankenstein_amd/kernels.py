@@ -253,6 +253,19 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
            ATTN_Q_PRESCALED if q_prescaled else 0, fk_dtype(q), _stream())
 
 
+def attn_combine(parts: Tensor, lse_parts: Optional[Tensor] = None, want_lse: bool = True):
+    """parts [B, S, T, H, D] (+ lse_parts [B, S, H, T]) -> (out [B, T, H, D], lse [B, H, T] or None): fk_attn_combine."""
+    B, S, T, H, D = parts.shape
+    assert parts.is_contiguous()
+    out = torch.empty((B, T, H, D), dtype=parts.dtype, device=parts.device)
+    lse = None
+    if lse_parts is not None:
+        assert lse_parts.dtype == torch.float32 and lse_parts.is_contiguous() and lse_parts.shape == (B, S, H, T)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=parts.device) if want_lse else None
+    call("fk_attn_combine", parts.data_ptr(), _ptr(lse_parts), out.data_ptr(), _ptr(lse), B, S, T, H, D, fk_dtype(parts), _stream())
+    return out, lse
+
+
 # ------------------------------------------------------------------------------------------- norms
 def norm_fwd(x: Tensor, gamma: Tensor, beta: Optional[Tensor], eps: float, kind: int = NORM_LAYER):
     x2 = _as2d(x)

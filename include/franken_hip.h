@@ -150,6 +150,14 @@ int fk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
 /* y = a + b (same dtype) */
 int fk_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
 
+/* fk_attn_combine: split-key attention.  A few queries against a long context (the perceiver's 32 learnable queries x 6144 tokens,
+ * models/brainformer.py:204-215) fill the chip only when the KEYS are split over workgroups: the caller runs fk_attn_fwd / fk_attn_bwd on
+ * views with the S key ranges folded into the batch dimension (queries replicated) and combines the partial results here.
+ * parts [B, S, T, H, D]; lse_parts [B, S, H, T] or NULL.  With lse_parts (forward): out[b] = sum_s softmax_s(lse_parts)[s] * parts[b, s] and
+ * lse_out [B, H, T] = log sum_s exp(lse_parts) (nullable).  Without (query gradient, already normalised by the global LSE): out = sum_s parts. */
+int fk_attn_combine(const void* parts, const float* lse_parts, void* out, float* lse_out, int64_t B, int64_t S, int64_t T, int64_t H,
+                    int64_t D, int dtype, void* stream);
+
 /* ---- single-token decode step with the position on the DEVICE (`pos`: int32[1]), so one captured hipGraph serves every new token
  * of GPT.generate (models/gpt2_model.py:328-353; the reference re-forwards the whole sequence per token).
  * fk_gpt_embed_step: out[b,:] = wte[idx[b],:] + wpe[*pos,:].   fk_kv_append: kv[b, *pos, :] = qkv[b, d:3d] (kv [B, tmax, 2d]).

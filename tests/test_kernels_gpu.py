@@ -837,3 +837,42 @@ def test_head_ce_fused_kernels(K, dtype, rows, V, Kd, bias):
     dw = K.gemm_nt(dlT, hT, out_dtype=torch.float32)[:V]
     want_dw = logits.grad.t() @ h
     close(dw, want_dw, dtype, atol32=1e-5, rtol32=1e-4, atol16=2e-3 * float(want_dw.abs().max()) + 1e-6, rtol16=3e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_split_key_attention_equals_the_single_pass(K, dtype):
+    """fk_attn_combine: a few queries against a long unmasked context (perceiver read-out, models/brainformer.py:204-215) with the keys
+    split into S ranges folded into the batch dimension — forward output / LSE and all three gradients equal the unsplit kernels
+    (the way engine.CrossAttnBranch runs it), and the fp32 result matches torch's SDPA."""
+    from frankenstein_amd import engine as E
+    B, T, H, D, Nc, S = 2, 32, 4, 64, 2048, 8
+    HD = H * D
+    qf = q(rnd(B, T, H, D, seed=1), dtype)
+    kvf = q(rnd(B, Nc, 2 * HD, seed=2), dtype)
+    dof = q(rnd(B, T, H, D, seed=3), dtype)
+    qd, kv, dod = dev(qf, dtype), dev(kvf, dtype), dev(dof, dtype)
+    kv3 = kv.view(B, Nc, 2 * HD)
+    k_, v_ = kv3[..., :HD].unflatten(-1, (H, D)), kv3[..., HD:].unflatten(-1, (H, D))
+    o1, l1 = K.attn_fwd(qd, k_, v_)
+    kvs = kv.view(B * S, Nc // S, 2 * HD)
+    ks, vs = kvs[..., :HD].unflatten(-1, (H, D)), kvs[..., HD:].unflatten(-1, (H, D))
+    o_s, l_s = K.attn_fwd(E._replicate(qd, S), ks, vs)
+    o2, l2 = K.attn_combine(o_s.view(B, S, T, H, D), l_s.view(B, S, H, T))
+    close(o2, o1, dtype, atol32=2e-6, rtol32=1e-5, atol16=1e-2)
+    torch.testing.assert_close(l2, l1, atol=1e-5, rtol=1e-5)
+    if dtype == torch.float32:
+        want = torch.nn.functional.scaled_dot_product_attention(qf.transpose(1, 2), kvf[..., :HD].view(B, Nc, H, D).transpose(1, 2),
+                                                                kvf[..., HD:].view(B, Nc, H, D).transpose(1, 2)).transpose(1, 2)
+        close(o2, want, dtype, atol32=2e-5, rtol32=1e-4)
+    # backward: unsplit vs split with the GLOBAL statistics
+    dq1, dkv1 = torch.empty_like(qd), torch.empty_like(kv)
+    d3 = dkv1.view(B, Nc, 2 * HD)
+    K.attn_bwd(qd, k_, v_, o1, dod, l1, dq1, d3[..., :HD].unflatten(-1, (H, D)), d3[..., HD:].unflatten(-1, (H, D)))
+    dkv2 = torch.empty_like(kv)
+    d2 = dkv2.view(B * S, Nc // S, 2 * HD)
+    dq_s = torch.empty((B * S, T, H, D), dtype=dtype, device="cuda")
+    K.attn_bwd(E._replicate(qd, S), ks, vs, E._replicate(o1, S), E._replicate(dod, S), E._replicate(l1, S), dq_s,
+               d2[..., :HD].unflatten(-1, (H, D)), d2[..., HD:].unflatten(-1, (H, D)))
+    dq2 = K.attn_combine(dq_s.view(B, S, T, H, D))[0]
+    close(dq2, dq1, dtype, atol32=2e-6, rtol32=1e-4, atol16=2e-2 * float(dq1.float().abs().max()))
+    close(dkv2, dkv1, dtype, atol32=2e-6, rtol32=1e-4, atol16=2e-2 * float(dkv1.float().abs().max()))
