@@ -434,10 +434,12 @@ def _replicate(x: Tensor, S: int) -> Tensor:
 
 
 def _key_splits(T: int, Nc: int, mask: Mask) -> int:
-    """Split-key attention for a few queries against a long unmasked context (the perceiver's read-out): with one workgroup per
-    (sample, head) 7 of its 8 waves idle and 192 workgroups sweep 6144 keys serially; S key ranges folded into the batch dimension give
-    S times the workgroups (fk_attn_combine merges the partial results)."""
-    if mask.kind != K.MASK_NONE or T > 128 or Nc < 1024 or os.environ.get("FK_ATTN_NO_SPLIT") is not None:
+    """Split-key attention for a few queries against a long unmasked context (the perceiver's read-out): S key ranges folded into the
+    batch dimension give S times the workgroups, fk_attn_combine merges the partial results.  OPT-IN (FK_ATTN_SPLIT=1): measured on cfg2
+    (32 queries x 6144 keys, B = 32) the forward goes 137 -> 100 us and the query gradient 127 -> 82 us per layer — both sit on the
+    60 us it takes to stream K and V (302 MB) once — and the five replicate / combine launches per layer give the 0.16 ms per step back
+    (profiles/r03_split_perceiver.md): no net gain, so the single-pass form stays the default."""
+    if os.environ.get("FK_ATTN_SPLIT") != "1" or mask.kind != K.MASK_NONE or T > 128 or Nc < 1024:
         return 1
     for S in (8, 4, 2):
         if Nc % (S * 128) == 0:
