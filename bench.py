@@ -33,6 +33,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 MFMA_PEAK_BF16 = 2.5e15          # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 FLOP_PER_FRAME = 1.8173e9        # cfg2 fwd+bwd algorithmic FLOPs per input frame (visible attention only)
+FLOP_PER_FRAME_CE = 1.8211e9     # ... with the CE head (25 tokens, V = 50257): + 0.75 GF/sample forward
 
 
 def cfg2_model(dtype="bf16", head="l1"):
@@ -131,9 +132,9 @@ def cpu_baseline(steps=2):
 
 def mfma_util_pmc():
     """MFMA-pipe busy fraction of the whole step and of the roofline kernels from the committed rocprofv3 counter pass
-    (profiles/r02_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); None if absent."""
+    (profiles/r03_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); None if absent."""
     try:
-        pm = json.load(open(ROOT / "profiles" / "r02_pmc_mfma_util.json"))
+        pm = json.load(open(ROOT / "profiles" / "r03_pmc_mfma_util.json"))
         ks = pm["kernels"]
         pick = lambda frag: next((round(v["mfma_util_pct"], 1) for k, v in ks.items() if frag in k), None)
         return {"whole_step_pct": round(pm["whole_trace"]["mfma_util_pct"], 1), "attn_bwd_dkdv_pct": pick("attn_bwd_dkdv"),
@@ -247,7 +248,7 @@ def parity_block():
     """bf16-vs-reference numbers at the benchmarked shape, measured by tests/test_models_gpu.py::test_cfg2_b1_bf16_vs_reference and
     committed under profiles/ (None when that file is absent)."""
     try:
-        return json.load(open(ROOT / "profiles" / "r02_parity_cfg2_bf16.json"))
+        return json.load(open(ROOT / "profiles" / "r03_parity_cfg2_bf16.json"))
     except Exception:
         return None
 
@@ -338,6 +339,7 @@ def main():
     if rank == 0:
         frames = B * T * world * args.steps
         value = frames / dt
+        fpf = FLOP_PER_FRAME_CE if args.head == "ce" else FLOP_PER_FRAME
         fams = {}
         for name, evs in (timers or {}).items():
             ms = [a.elapsed_time(b) for a, b in evs]
@@ -354,14 +356,14 @@ def main():
             avg_s = tot / cnt / 1e3
             traffic = None
             try:   # HBM bytes per call from the committed rocprofv3 PMC passes (FETCH_SIZE x2 corrected + WRITE_SIZE)
-                pm = json.load(open(ROOT / "profiles" / "r02_pmc_traffic.json"))
+                pm = json.load(open(ROOT / "profiles" / "r03_pmc_traffic.json"))
                 traffic = pm["fk_attn_bwd_bytes_per_call"] if bwd else None
             except Exception:
                 pass
             roof = {"kernel": "fk_attn_bwd (attn_bwd_dq [+ delta] and attn_bwd_dkdv launches of one call)" if bwd else "fk_attn_fwd",
                     "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(fl / avg_s / MFMA_PEAK_BF16, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r02_pmc_traffic.json); algorithmic bytes 1.21e9 with every tensor counted once; the two deterministic kernels (dQ, dK/dV) each have to read Q, K, V, dO, so their compulsory traffic is 1.82e9",
+                    "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r03_pmc_traffic.json); algorithmic bytes 1.21e9 with every tensor counted once; the two deterministic kernels (dQ, dK/dV) each have to read Q, K, V, dO, so their compulsory traffic is 1.82e9",
                     "flops_per_launch": fl, "avg_launch_ms": round(avg_s * 1e3, 3)}
         out = {
             "metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "value": round(value, 1), "unit": "frames/s",
@@ -373,11 +375,11 @@ def main():
                                    "fwd+bwd+clip+AdamW", "per_gpu_batch": B, "global_batch": B * world, "frames_T": T,
                        "electrodes": Cn, "parallelism": f"dp{world}", "weights": "random-init (seed 42)"},
             "roofline": roof,
-            "step_roofline": {"bound": "mfma", "achieved": round(value / world * FLOP_PER_FRAME / 1e12, 2),
+            "step_roofline": {"bound": "mfma", "achieved": round(value / world * fpf / 1e12, 2),
                               "mfma_util_pmc": mfma_util_pmc(),
                               "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                              "frac": round(value / world * FLOP_PER_FRAME / MFMA_PEAK_BF16, 4),
-                              "note": "whole step per GPU: frames/s x 1.8173 GFLOP/frame (SURVEY §8d)"},
+                              "frac": round(value / world * fpf / MFMA_PEAK_BF16, 4),
+                              "note": f"whole step per GPU: frames/s x {fpf / 1e9:.4f} GFLOP/frame (SURVEY §8d)"},
             "dp": dp, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS") if world > 1 else None,
             "kernel_families": detail,
             "loss": round(float(loss), 5),

@@ -773,7 +773,7 @@ def test_vq_plus_brainformer_pipeline_bf16():
         fa.set_compute_dtype("fp32")
 
 
-def test_overlap_wgrad_gives_the_same_bits():
+def test_overlap_wgrad_gives_the_same_bits(monkeypatch):
     """The weight-gradient side stream (FusedAdamW(overlap_wgrad=True) / FK_WGRAD_STREAM=1: dW GEMMs beside the dX chain) changes where
     kernels run, not what they compute: on the ragged shape where round 2 saw run-to-run differences (compiler-packed fp32 in the RoPE
     epilogues beside a co-resident GEMM) two runs with the stream on and one with it off end with identical parameters."""
@@ -781,6 +781,8 @@ def test_overlap_wgrad_gives_the_same_bits():
     from frankenstein_amd.models import brainformer as bf
     from frankenstein_amd.utils import train_utils as tu
     fa.set_compute_dtype("bf16")
+    monkeypatch.delenv("FK_WGRAD_STREAM", raising=False)      # the suite may run with the stream forced on: this test sets it per run
+    E.enable_wgrad_stream(False)
     try:
         enc = bf.MAEConfig(window_size=475, n_electrodes=256, patch_size=25, dim=320, n_layers=2, head_dim=64, hidden_dim=840,
                            n_heads=5, n_kv_heads=5)

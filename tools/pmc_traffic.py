@@ -29,7 +29,9 @@ for name in fetch:
     if not w:
         continue
     res[name] = {"launches": len(f), "read_bytes": int(sum(f) / len(f) * 1024 * 2), "write_bytes": int(sum(w) / len(w) * 1024)}
-bwd = [k for k in res if "attn_bwd_dkdv_asm" in k] + [k for k in res if "attn_bwd_dq_asm" in k]    # the kernels the benchmark step's encoder layers run
+bwd = [k for k in res if "attn_bwd_dkdvw_asm" in k] + [k for k in res if "attn_bwd_dq_asm" in k]    # the kernels the benchmark step's encoder layers run
+if len(bwd) != 2:
+    bwd = [k for k in res if "attn_bwd_dkdv_asm" in k] + [k for k in res if "attn_bwd_dq_asm" in k]
 if len(bwd) != 2:
     bwd = [k for k in res if "attn_bwd_dkdv_ps" in k] + [k for k in res if "attn_bwd_dq_ps" in k]
 if not bwd:
