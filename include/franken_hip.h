@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FK_VERSION 200
+#define FK_VERSION 300
 
 #define FK_OK 0
 #define FK_EINVAL (-1)       /* bad shape / dtype / alignment / null pointer */
