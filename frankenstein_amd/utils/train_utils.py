@@ -139,7 +139,8 @@ class GradSync:
     1/world is folded into the optimizer kernel) as soon as every parameter of the bucket has its gradient,
     asynchronously on the process group's communication stream, so the exchange overlaps the remaining backward."""
 
-    def __init__(self, arena: ParamArena, group=None, bucket_bytes: int = 8 << 20, always: bool = False, measure: bool = False):
+    def __init__(self, arena: ParamArena, group=None, bucket_bytes: int = 8 << 20, always: bool = False, measure: bool = False,
+                 register: bool = True):
         import torch.distributed as dist
         self.dist, self.group, self.arena = dist, group, arena
         # measure=True: bracket the wait for the buckets in finish() with timestamps on the compute stream (HIP events; wall clock for
@@ -168,9 +169,10 @@ class GradSync:
             # replicas start from rank 0's parameters: what wrapping the model in DDP does in the reference
             # (accelerator.prepare, utils/train_utils.py:122) — identical seeds are not relied upon
             self.broadcast_parameters()
-            for i, p in enumerate(arena.params):
-                hook = self._make_hook(self.bucket_of[i])
-                p.register_post_accumulate_grad_hook(hook)     # also fires when engine.wgrad wrote the gradient itself
+            if register:                                       # (FusedAdamW calls on_grad from its own per-parameter hook instead: one
+                for i, p in enumerate(arena.params):           # Python hook per parameter costs ~5 us of host time per backward)
+                    hook = self._make_hook(self.bucket_of[i])
+                    p.register_post_accumulate_grad_hook(hook)     # also fires when engine.wgrad wrote the gradient itself
 
     def _mark(self):
         if self.arena.grad.is_cuda:
@@ -195,6 +197,15 @@ class GradSync:
             gsrc = self.dist.get_global_rank(self.group, src) if self.group is not None else src
             self.dist.broadcast(self.arena.flat, src=gsrc, group=self.group)
             E.bump_weight_epoch()
+
+    def on_grad(self, i: int) -> None:
+        """parameter i of the arena has its gradient: counts towards its bucket, which goes out when complete"""
+        if not (self.active and self.enabled):
+            return
+        b = self.bucket_of[i]
+        self._pending[b] += 1
+        if self._pending[b] == self.buckets[b][2]:
+            self._launch(b)
 
     def _make_hook(self, b: int):
         def hook(_param):
@@ -267,13 +278,18 @@ class FusedAdamW:
         # fires when engine.wgrad / engine.norm_bwd wrote the gradient into the arena themselves).
         self._touched = [False] * len(self.arena.params)
         self._lag: Optional[List[int]] = None       # per parameter: optimizer steps it sat out (None: no parameter ever did)
+        self.sync = GradSync(self.arena, group, bucket_bytes, always=sync_always, register=False)
         for i, p in enumerate(self.arena.params):
             p.register_post_accumulate_grad_hook(self._make_touch_hook(i))
-        self.sync = GradSync(self.arena, group, bucket_bytes, always=sync_always)
 
     def _make_touch_hook(self, i: int):
-        def hook(_param):
-            self._touched[i] = True
+        if self.sync.active:
+            def hook(_param):                  # one hook per parameter serves both: "reached by the backward" and the bucket's readiness
+                self._touched[i] = True
+                self.sync.on_grad(i)
+        else:
+            def hook(_param):
+                self._touched[i] = True
         return hook
 
     def mark_touched(self, flags=None) -> None:
