@@ -14,7 +14,7 @@ import os
 LIB_PATH = Path(os.environ.get("FRANKEN_HIP_LIB") or Path(__file__).resolve().parent / "libfranken_hip.so")
 
 FK_F32, FK_BF16 = 0, 1
-MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL, MASK_PREFIX, MASK_KEYPAD = 0, 1, 2, 3, 4
+MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL, MASK_PREFIX, MASK_KEYPAD, MASK_DENSE = 0, 1, 2, 3, 4, 5
 NORM_LAYER, NORM_RMS = 0, 1
 ATTN_Q_PRESCALED = 1
 

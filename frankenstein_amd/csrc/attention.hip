@@ -63,9 +63,14 @@ FK_DEV bool visible(int kind, int c, int qpos, int kpos) {
   return true;
 }
 // exclusive upper bound of key INDICES visible to query index q (monotone predicates only)
+// FK_MASK_DENSE: an arbitrary boolean mask (models/brainformer.py:160-168 passes whatever it is given): `limits` points to uint8
+// [Bm, Nq, Nk] (non-zero = attend), mask_c is the batch stride in elements (0: one mask for every sample); heads share it
+FK_DEV bool dense_vis(const AttnArgs& p, int b, int q, int k) {
+  return reinterpret_cast<const unsigned char*>(p.limits)[(int64_t)b * p.mask_c + (int64_t)q * p.Nk + k] != 0;
+}
 FK_DEV int kv_limit(const AttnArgs& p, int b, int q) {
   if (p.mask_kind == FK_MASK_PREFIX) return min(p.Nk, p.limits[(int64_t)b * p.Nq + q]);
-  if (p.mask_kind == FK_MASK_KEYPAD) return 0;        // no structure: every tile takes the per-element path
+  if (p.mask_kind == FK_MASK_KEYPAD || p.mask_kind == FK_MASK_DENSE) return 0;        // no structure: every tile takes the per-element path
   const int qpos = q + p.q_off;
   if (p.mask_kind == FK_MASK_CAUSAL) return min(p.Nk, max(0, qpos - p.k_off + 1));
   if (p.mask_kind == FK_MASK_BLOCK_CAUSAL) return min(p.Nk, max(0, (qpos / p.mask_c + 1) * p.mask_c - p.k_off));
@@ -74,7 +79,7 @@ FK_DEV int kv_limit(const AttnArgs& p, int b, int q) {
 // smallest query INDEX that can see key index k
 FK_DEV int q_first(const AttnArgs& p, int b, int k) {
   if (p.mask_kind == FK_MASK_PREFIX) return p.qfirst[(int64_t)b * p.Nk + k];
-  if (p.mask_kind == FK_MASK_KEYPAD) return 0x3fffffff;   // 'no query sees every key for free' -> always the predicate path
+  if (p.mask_kind == FK_MASK_KEYPAD || p.mask_kind == FK_MASK_DENSE) return 0x3fffffff;   // 'no query sees every key for free' -> always the predicate path
   const int kpos = k + p.k_off;
   if (p.mask_kind == FK_MASK_CAUSAL) return max(0, kpos - p.q_off);
   if (p.mask_kind == FK_MASK_BLOCK_CAUSAL) return max(0, (kpos / p.mask_c) * p.mask_c - p.q_off);
@@ -386,6 +391,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   const int qrow = q0 + wave * 32 + li;
   const bool q_ok = qrow < p.Nq;
   const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const bool dense = p.mask_kind == FK_MASK_DENSE;
   const int my_lim = ((prefix || keypad) && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;   // prefix length / query validity
 
   if constexpr (C::DPAD != D) {   // zero the padded columns of the K/V images once (never restaged)
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   }
 
   const int q_last = min(q0 + BQ, p.Nq) - 1;
-  const int kv_end = p.mask_kind == FK_MASK_KEYPAD ? p.Nk : kv_limit(p, b, q_last);
+  const int kv_end = (p.mask_kind == FK_MASK_KEYPAD || p.mask_kind == FK_MASK_DENSE) ? p.Nk : kv_limit(p, b, q_last);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   // first key index that is NOT visible to every query row of this wave (tiles below need no mask test)
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kb + 32 * u + acc_row(r, lh);
-          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))))) sc[u][r] = -INFINITY;
+          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : (dense ? (q_ok && dense_vis(p, b, qrow, key)) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))))) sc[u][r] = -INFINITY;
         }
     }
     float tmax = -INFINITY;
@@ -573,6 +579,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   const int qrow = q0 + wave * 32 + li;
   const bool q_ok = qrow < p.Nq;
   const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const bool dense = p.mask_kind == FK_MASK_DENSE;
   const int my_lim = ((prefix || keypad) && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;   // prefix length / query validity
 
   if constexpr (C::DPAD != D) {   // padded columns feed the transposed K reads: keep them zero
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   }
 
   const int q_last = min(q0 + BQ, p.Nq) - 1;
-  const int kv_end = p.mask_kind == FK_MASK_KEYPAD ? p.Nk : kv_limit(p, b, q_last);
+  const int kv_end = (p.mask_kind == FK_MASK_KEYPAD || p.mask_kind == FK_MASK_DENSE) ? p.Nk : kv_limit(p, b, q_last);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
   const int full_vis_end = kv_limit(p, b, wave_q_first);
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) {
           float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
           const int key = kb + 32 * u + acc_row(r, lh);
-          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off))))) pv = 0.0f;
+          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : (dense ? (q_ok && dense_vis(p, b, qrow, key)) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))))) pv = 0.0f;
           sc[r] = pv * (dp[r] - dl);   // dS^T (without the softmax scale; folded into the final store)
         }
       }
@@ -749,6 +756,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   const int krow = k0 + wave * 32 + li;
   const bool k_ok = krow < p.Nk;
   const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
+  const bool dense = p.mask_kind == FK_MASK_DENSE;
   const int my_qf = ((prefix || keypad) && k_ok) ? p.qfirst[(int64_t)b * p.Nk + krow] : 0;     // first query / key validity
 
   if constexpr (C::DPAD != D) {
@@ -768,7 +776,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
     }
   }
 
-  const int qs = p.mask_kind == FK_MASK_KEYPAD ? 0 : (q_first(p, b, k0) / TQ) * TQ;                 // first query tile that can see key k0
+  const int qs = (p.mask_kind == FK_MASK_KEYPAD || p.mask_kind == FK_MASK_DENSE) ? 0 : (q_first(p, b, k0) / TQ) * TQ;   // first query tile that can see key k0
   const int ntiles = qs < p.Nq ? (p.Nq - qs + TQ - 1) / TQ : 0;
   // queries >= this index see every key of this wave's 32 keys
   const int full_vis_q = q_first(p, b, min(k0 + wave * 32 + 31, p.Nk - 1));
@@ -887,7 +895,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
             const int r = 4 * g + j;
             float pv = __builtin_amdgcn_exp2f(sc[u][r] * c + l4[j]);
             const int q = qb + 32 * u + acc_row(r, lh);
-            if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos))))) pv = 0.0f;
+            if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : (dense ? (q < p.Nq && dense_vis(p, b, q, krow)) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos)))))) pv = 0.0f;
             sc[u][r] = pv;
             dp[u][r] = pv * (dp[u][r] + d4[j]);
           }
@@ -2224,8 +2232,9 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
                "%s: head_dim %lld unsupported (8/16/32/64, 128 for bf16)", name, (long long)D);
   FK_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B < 65536 && H < 65536 && Nq < (1LL << 30) && Nk < (1LL << 30) && B * H * ((Nq + 127) / 128) < (1LL << 31) && B * H * ((Nk + 127) / 128) < (1LL << 31),
                "%s: bad shape B=%lld H=%lld Nq=%lld Nk=%lld", name, (long long)B, (long long)H, (long long)Nq, (long long)Nk);
-  FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL || mask_kind == FK_MASK_PREFIX || mask_kind == FK_MASK_KEYPAD,
-               "%s: mask kind %d not supported", name, mask_kind);
+  FK_CHECK_ARG(mask_kind == FK_MASK_NONE || mask_kind == FK_MASK_CAUSAL || mask_kind == FK_MASK_BLOCK_CAUSAL || mask_kind == FK_MASK_PREFIX || mask_kind == FK_MASK_KEYPAD ||
+               mask_kind == FK_MASK_DENSE, "%s: mask kind %d not supported", name, mask_kind);
+  FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (mask_c >= 0 && mask_c < (1LL << 31) && Nq * Nk < (1LL << 31)), "%s: dense mask too large", name);
   FK_CHECK_ARG(mask_kind != FK_MASK_BLOCK_CAUSAL || mask_c > 0, "%s: block-causal mask needs block size > 0", name);
   const int vec = dtype == FK_BF16 ? 8 : 4;
   for (int i = 0; i < nstr; ++i)
@@ -2289,6 +2298,7 @@ int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
   a.B = (int)B; a.H = (int)H; a.Nq = (int)Nq; a.Nk = (int)Nk;
   a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
   FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_fwd: prefix / key-padding masks need both tables");
+  FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (limits && !(flags & FK_ATTN_Q_PRESCALED)), "fk_attn_fwd: a dense mask needs its uint8 table in `limits` and the generic kernels (no FK_ATTN_Q_PRESCALED)");
   a.limits = limits; a.qfirst = qfirst; a.flags = flags;
   FK_ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_fwd");
@@ -2318,6 +2328,7 @@ int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
   FK_CHECK_ARG(!rope_table || (Nq == Nk && D % 4 == 0 && ((uintptr_t)rope_table & 15) == 0), "fk_attn_bwd: fused inverse RoPE needs self-attention (Nq == Nk)");
   a.rope_table = rope_table; a.rope_bs = rope_bs; a.rope_off = (int)rope_off;
   FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_bwd: prefix / key-padding masks need both tables");
+  FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (limits && !(flags & FK_ATTN_Q_PRESCALED)), "fk_attn_bwd: a dense mask needs its uint8 table in `limits` and the generic kernels (no FK_ATTN_Q_PRESCALED)");
   a.limits = limits; a.qfirst = qfirst; a.flags = flags;
   FK_ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_bwd");

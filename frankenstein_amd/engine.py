@@ -360,7 +360,7 @@ class AttnBranch(torch.autograd.Function):
         bq = None if qkv_b is None else shadow([qkv_b])
         prescale = False
         if rope is not None and D % 8 == 0 and (3 * HD) % 8 == 0:     # RoPE fused into the projection epilogue
-            prescale = _attn_prescale(D)
+            prescale = _attn_prescale(D) and mask.kind != K.MASK_DENSE          # dense masks run on the generic kernels
             if prescale:
                 tab, qtab = rope.pair((1.0 / math.sqrt(D)) * 1.4426950408889634)
                 qkv = K.gemm_nt_rope(h, shadow(qkv_w), bq, tab, N, rope.pos_off(N), D, 2 * HD, q_cols=HD, q_table=qtab)

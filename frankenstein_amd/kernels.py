@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_KEYPAD, MASK_NONE, MASK_PREFIX, NORM_LAYER, NORM_RMS, ATTN_Q_PRESCALED, call, lib
+from ._lib import FK_BF16, FK_F32, MASK_BLOCK_CAUSAL, MASK_CAUSAL, MASK_DENSE, MASK_KEYPAD, MASK_NONE, MASK_PREFIX, NORM_LAYER, NORM_RMS, ATTN_Q_PRESCALED, call, lib
 
 Tensor = torch.Tensor
 
@@ -185,8 +185,20 @@ class Mask:
         self.kind, self.c, self.q_off, self.k_off, self.limits, self.qfirst = kind, c, q_off, k_off, limits, qfirst
 
     def sliced(self, n_full_q: int, n_full_k: int, t_q: int, t_k: int) -> "Mask":
-        assert self.kind not in (MASK_PREFIX, MASK_KEYPAD) or (n_full_q == t_q and n_full_k == t_k), "table masks cannot be sliced"
+        assert self.kind not in (MASK_PREFIX, MASK_KEYPAD, MASK_DENSE) or (n_full_q == t_q and n_full_k == t_k), "table masks cannot be sliced"
         return Mask(self.kind, self.c, self.q_off + n_full_q - t_q, self.k_off + n_full_k - t_k, self.limits, self.qfirst)
+
+    @staticmethod
+    def from_dense(mask: Tensor, t_q: int, t_k: int) -> "Mask":
+        """Any boolean mask (True = attend) of shape [.., N_q, N_k] with at most one non-unit leading dimension (the batch; heads share the
+        mask): the reference's attention takes whatever tensor it is given and slices it as mask[..., -t_q:, -t_k:]
+        (models/brainformer.py:160-168).  Stored as uint8 [Bm, t_q, t_k] for the per-element path of the generic kernels."""
+        m = mask[..., mask.shape[-2] - t_q:, mask.shape[-1] - t_k:]
+        lead = [d for d in m.shape[:-2] if d != 1]
+        assert len(lead) <= 1, f"dense attention mask with more than one batch-like dimension: {tuple(mask.shape)}"
+        bm = lead[0] if lead else 1
+        u8 = m.reshape(bm, t_q, t_k).to(torch.uint8).contiguous()
+        return Mask(MASK_DENSE, 0 if bm == 1 else t_q * t_k, 0, 0, u8, None)
 
     @staticmethod
     def from_padding(q_valid: Tensor, k_valid: Tensor) -> "Mask":

@@ -90,9 +90,13 @@ def resolve_mask(attn_mask, t_q: int, t_k: int) -> Mask:
         return attn_mask
     m = getattr(attn_mask, "_fk_mask", None)
     if m is None:
-        raise NotImplementedError(
-            "frankenstein_amd attention takes analytic masks (None, causal, block-causal built by "
-            "build_advanced_causal_mask / Encoder.attn_mask); an arbitrary dense boolean mask is not supported")
+        # an arbitrary boolean tensor (the reference hands whatever it is given to SDPA, models/brainformer.py:160-168): the per-element
+        # path of the generic kernels reads it as uint8.  The masks the reference itself builds are tagged and never come here.
+        assert attn_mask.dtype == torch.bool, "attention masks are boolean (True = attend)"
+        dm = Mask.from_dense(attn_mask, t_q, t_k)
+        if not dm.limits.is_cuda and torch.cuda.is_available():
+            dm.limits = dm.limits.cuda()
+        return dm
     return m.sliced(attn_mask.shape[-2], attn_mask.shape[-1], t_q, t_k)   # mask[..., -t_q:, -t_k:]
 
 

@@ -31,7 +31,7 @@ extern "C" {
 #define FK_EUNSUPPORTED (-3)
 
 enum { FK_F32 = 0, FK_BF16 = 1 };
-enum { FK_MASK_NONE = 0, FK_MASK_CAUSAL = 1, FK_MASK_BLOCK_CAUSAL = 2, FK_MASK_PREFIX = 3, FK_MASK_KEYPAD = 4 };
+enum { FK_MASK_NONE = 0, FK_MASK_CAUSAL = 1, FK_MASK_BLOCK_CAUSAL = 2, FK_MASK_PREFIX = 3, FK_MASK_KEYPAD = 4, FK_MASK_DENSE = 5 };
 /* fk_attn_* flags.  FK_ATTN_Q_PRESCALED: Q already holds scale * log2(e) * q (written so by fk_gemm_nt_rope's pre-scaled query
  * table), bf16 with D = 64 only: the kernels then work in the exp2 domain with the row constants (running reference maximum,
  * -LSE, -delta) as the initial MFMA accumulators, i.e. without any per-score multiply / subtract.  dQ, dK, dV are the same
@@ -86,7 +86,9 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
  * PREFIX (per-sample masks of sorted token subsets, MAE's get_sub_att_matrix models/brainformer.py:392-413):
  * visible(q,k) = k < limits[b,q] <=> q >= qfirst[b,k], int32 tables from fk_prefix_mask.
  * KEYPAD (padding mask of models/simple_mae:228-236,349-352): visible(q,k) = limits[b,q] != 0 && qfirst[b,k] != 0, i.e. the two
- * int32 tables are the query / key validity flags.  Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
+ * int32 tables are the query / key validity flags.  DENSE (any boolean mask: models/brainformer.py:160-168 passes whatever it is given):
+ * `limits` points to uint8 [Bm, Nq, Nk] (non-zero = attend; heads share it), mask_c = its batch stride in elements (0: one mask for every
+ * sample), qfirst unused; every tile takes the per-element path of the generic kernels (FK_ATTN_Q_PRESCALED is refused).  Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
  * Q/K/V's strides; delta_ws is fp32 scratch of 2 * B * H * roundup(Nq, 64) floats (the row statistics the dQ kernel hands to the dK/dV kernel).  rope_table != NULL (self-attention only) additionally applies the
  * inverse RoPE (rotation by -angle at position rope_off + index) to dQ and dK as they are stored = apply_rope's backward.                                                        */
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,

@@ -643,6 +643,71 @@ def test_attention_prefix_mask_from_token_ids(K, dtype):
     close(dv, vr.grad, dtype, atol32=5e-5, atol16=4e-2)
 
 
+DENSE_CASES = [
+    # B, H, Nq, Nk, D, one mask per sample
+    (2, 2, 200, 200, 64, True),
+    (1, 3, 57, 300, 32, False),
+    (2, 2, 128, 256, 16, True),
+    (3, 2, 8, 8, 8, False),
+    (2, 1, 320, 192, 64, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", DENSE_CASES)
+def test_attention_dense_boolean_mask(K, dtype, case):
+    """FK_MASK_DENSE: any boolean mask, as the reference's attention hands it to SDPA (models/brainformer.py:160-168); heads share it,
+    the batch may or may not.  Rows whose first key tiles are wholly masked and keys no query sees are part of the case."""
+    B, H, Nq, Nk, D, per_sample = case
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    mt = torch.rand(B if per_sample else 1, 1, Nq, Nk, generator=g) < 0.35
+    mt[..., : min(96, Nk - 1)] &= (torch.arange(Nq) % 3 != 0)[:, None]      # every third query: nothing visible in the first key tiles
+    mt[..., Nk // 2] = False                                                 # a key without any query
+    mt[..., Nk - 1] = True                                                   # and no empty row (NaN in the reference)
+    m = K.Mask.from_dense(mt.cuda(), Nq, Nk)
+    assert m.limits.dtype == torch.uint8 and m.c == (Nq * Nk if per_sample and B > 1 else 0)
+    qv, kv, vv, do = rnd(B, Nq, H, D, seed=1), rnd(B, Nk, H, D, seed=2), rnd(B, Nk, H, D, seed=3), rnd(B, Nq, H, D, seed=4)
+    qd, kd, vd = dev(qv, dtype), dev(kv, dtype), dev(vv, dtype)
+    o, lse = K.attn_fwd(qd, kd, vd, m)
+    qr, kr, vr = (q(t_, dtype).requires_grad_(True) for t_ in (qv, kv, vv))
+    oref = ref_attn(qr, kr, vr, mt)
+    close(o, oref, dtype, atol32=2e-5, atol16=2e-2)
+    oref.backward(q(do, dtype))
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    K.attn_bwd(qd, kd, vd, o, dev(do, dtype), lse, dq, dk, dv, m)
+    close(dq, qr.grad, dtype, atol32=5e-5, atol16=4e-2)
+    close(dk, kr.grad, dtype, atol32=5e-5, atol16=4e-2)
+    close(dv, vr.grad, dtype, atol32=5e-5, atol16=4e-2)
+    assert float(dk[:, Nk // 2].abs().max()) == 0.0 and float(dv[:, Nk // 2].abs().max()) == 0.0
+
+
+def test_attention_dense_mask_agrees_with_the_analytic_kinds(K):
+    """The same visibility given as a table and as a rule: same kernels, same tile order -> the same bits (fp32), and a wholly masked
+    query row gives 0 (the documented difference from SDPA's NaN) with zero gradients."""
+    B, H, N, D, Cb = 2, 2, 192, 32, 16
+    qv, kv, vv, do = (dev(rnd(B, N, H, D, seed=s), torch.float32) for s in (1, 2, 3, 4))
+    mt = mask_tensor(2, Cb, N, N)
+    outs = []
+    for m in (K.Mask(2, Cb), K.Mask.from_dense(mt.cuda(), N, N)):
+        o, lse = K.attn_fwd(qv, kv, vv, m)
+        dq, dk, dv = torch.empty_like(qv), torch.empty_like(kv), torch.empty_like(vv)
+        K.attn_bwd(qv, kv, vv, o, do, lse, dq, dk, dv, m)
+        outs.append((o, lse, dq, dk, dv))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    mt = mt.clone()
+    mt[5] = False
+    m = K.Mask.from_dense(mt.cuda(), N, N)
+    o, lse = K.attn_fwd(qv, kv, vv, m)
+    dq, dk, dv = torch.empty_like(qv), torch.empty_like(kv), torch.empty_like(vv)
+    K.attn_bwd(qv, kv, vv, o, do, lse, dq, dk, dv, m)
+    assert float(o[:, 5].abs().max()) == 0.0 and float(dq[:, 5].abs().max()) == 0.0
+    assert all(bool(torch.isfinite(t_).all()) for t_ in (o, dq, dk, dv))
+    from frankenstein_amd._lib import FrankenHipError
+    with pytest.raises(FrankenHipError, match="dense mask"):
+        K.attn_fwd(qv.bfloat16().repeat(1, 1, 1, 2), kv.bfloat16().repeat(1, 1, 1, 2), vv.bfloat16().repeat(1, 1, 1, 2), m, q_prescaled=True)
+
+
 def test_shadow_refresh_single_launch(K):
     """fk_cast_pack_multi (engine.refresh_shadows): every weight shadow re-packed in one launch == the per-weight packs."""
     import frankenstein_amd as fa

@@ -430,8 +430,18 @@ def test_standalone_modules_match_oracle():
     hs = h[:, :48]
     want = R.block(sd, "encoder.transformer.h.0.", hs, e, R.block_causal_mask(128, 16), ang)
     torch.testing.assert_close(blk(hs.cuda().contiguous(), attn_mask=mask, rope=rope).cpu(), want, atol=1e-4, rtol=1e-4)
-    with pytest.raises(NotImplementedError):
-        blk(h.cuda(), attn_mask=torch.ones(128, 128, dtype=torch.bool, device="cuda"), rope=rope)
+    # an arbitrary (untagged) boolean mask goes through the dense-mask kernels: [N, N] sliced like the buffer, and one mask per sample
+    gm = torch.Generator().manual_seed(5)
+    dm = torch.rand(128, 128, generator=gm) < 0.4
+    dm[:, 100] = True                                  # every query sees a key (a fully masked row is NaN in the reference)
+    want = R.block(sd, "encoder.transformer.h.0.", h, e, dm, ang)
+    torch.testing.assert_close(blk(h.cuda(), attn_mask=dm.cuda(), rope=rope).cpu(), want, atol=1e-4, rtol=1e-4)
+    want = R.block(sd, "encoder.transformer.h.0.", hs, e, dm, ang)
+    torch.testing.assert_close(blk(hs.cuda().contiguous(), attn_mask=dm.cuda(), rope=rope).cpu(), want, atol=1e-4, rtol=1e-4)
+    dmb = torch.rand(2, 1, 128, 128, generator=gm) < 0.5
+    dmb[..., 7] = True
+    want = R.block(sd, "encoder.transformer.h.0.", h, e, dmb, ang)
+    torch.testing.assert_close(blk(h.cuda(), attn_mask=dmb.cuda(), rope=rope).cpu(), want, atol=1e-4, rtol=1e-4)
     q = torch.randn(2, 8, 64, generator=torch.Generator().manual_seed(4))
     cb = m.perceiver.h[0]
     want = R.cross_attention(sd, "perceiver.h.0.cross_attn.", q, h, 4, 8)
