@@ -18,7 +18,7 @@ MASK_NONE, MASK_CAUSAL, MASK_BLOCK_CAUSAL, MASK_PREFIX, MASK_KEYPAD, MASK_DENSE 
 NORM_LAYER, NORM_RMS = 0, 1
 ATTN_Q_PRESCALED = 1
 
-_p, _i64, _int, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_size_t
+_p, _i64, _int, _f32, _f64, _sz, _u32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint32
 
 # name -> (restype, argtypes); mirrors include/franken_hip.h one to one
 SIGNATURES = {
@@ -34,6 +34,9 @@ SIGNATURES = {
     "fk_colsum": (_int, [_p, _i64, _p, _i64, _i64, _int, _int, _p, _sz, _p]),
     "fk_attn_fwd": (_int, [_p, _p, _p, _p, _p] + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _int, _int, _p]),
     "fk_attn_bwd": (_int, [_p] * 10 + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _p, _i64, _i64, _int, _int, _p]),
+    "fk_attn_fwd_dropout": (_int, [_p, _p, _p, _p, _p] + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _int, _f32, _p, _u32, _int, _p]),
+    "fk_attn_bwd_dropout": (_int, [_p] * 10 + [_i64] * 13 + [_int, _i64, _i64, _i64, _p, _p, _f32, _p, _i64, _i64, _int, _f32, _p, _u32, _int, _p]),
+    "fk_dropout": (_int, [_p, _p, _p, _i64, _f32, _p, _u32, _int, _p]),
     "fk_norm_fwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _int, _int, _p]),
     "fk_norm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "fk_norm_bwd": (_int, [_p] * 9 + [_i64, _i64, _int, _int, _int, _p, _sz, _p]),

@@ -42,6 +42,9 @@ struct AttnArgs {
   // from sorted per-token block ids: the per-sample sub-mask of MAE, models/brainformer.py:392-413)
   const int* limits; const int* qfirst;
   int flags;          // FK_ATTN_Q_PRESCALED
+  // dropout on the attention probabilities (fk_attn_*_dropout; generic kernels only): keep <=> bits >= drop_thresh, kept entries times
+  // drop_scale = 1 / (1 - p); seed words in device memory (fk_common.h "dropout").  drop_thresh == 0: no dropout.
+  const unsigned* drop_seed; unsigned drop_site, drop_thresh; float drop_scale;
 };
 
 template <typename T, int D> struct AT {
@@ -441,6 +444,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   float m = -INFINITY, l = 0.0f;
   f32x16 o[C::DT];
   zero_acc(o);
+  DropKey dkey{};
+  unsigned drow = 0;
+  if (p.drop_thresh) {
+    dkey = drop_key(p.drop_seed, p.drop_site, p.drop_thresh);
+    drow = drop_row(dkey, (unsigned)((b * p.H + hd) * p.Nq + qrow));
+  }
 
   int slot = 0;
   for (int t = 0; t < ntiles; ++t) {
@@ -520,6 +529,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
         rs += pv;
       }
     l += rs;
+    if (p.drop_thresh) {             // wave-uniform: the row sum above is the softmax's (undropped); O takes the kept entries only
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!drop_keep(dkey, drow, (unsigned)(kb + 32 * u + acc_row(r, lh)))) sc[u][r] = 0.0f;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -546,7 +562,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
   }
 
   const float lt = l + __shfl_xor(l, 32, 64);
-  const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;   // fully masked row -> 0 (torch >= 2.1 CPU semantics)
+  const float inv = lt > 0.0f ? (p.drop_thresh ? p.drop_scale : 1.0f) / lt : 0.0f;   // fully masked row -> 0 (torch >= 2.1 CPU semantics)
   T* Op = (T*)p.Out + (int64_t)b * p.o_bs + hd * D;
   store_rows_T<T, D>(Op, p.o_rs, qrow, q_ok, o, inv, lh);
   if (q_ok && lh == 0 && p.LSE)
@@ -647,6 +663,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
   const float c = p.scale * LOG2E;
   f32x16 dq[C::DT];
   zero_acc(dq);
+  DropKey dkey{};
+  unsigned drow = 0;
+  if (p.drop_thresh) {
+    dkey = drop_key(p.drop_seed, p.drop_site, p.drop_thresh);
+    drow = drop_row(dkey, (unsigned)((b * p.H + hd) * p.Nq + qrow));
+  }
 
   // the tile loop is unrolled by the ring depth so that the LDS slot is a compile-time constant: every fragment read then carries its slot
   // offset in the instruction's immediate field instead of a per-read v_add_u32 (VALU issue is what bounds these kernels)
@@ -664,7 +686,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
     }
     const char* kt = kimg(SLOT);
     const char* vt = vimg(SLOT);
-    const bool boundary = kb + BKV > full_vis_end;
+    const bool boundary = kb + BKV > full_vis_end || p.drop_thresh != 0;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f32x16 sc, dp;
@@ -699,7 +721,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
           float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
           const int key = kb + 32 * u + acc_row(r, lh);
           if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : (dense ? (q_ok && dense_vis(p, b, qrow, key)) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))))) pv = 0.0f;
-          sc[r] = pv * (dp[r] - dl);   // dS^T (without the softmax scale; folded into the final store)
+          float dpv = dp[r];
+          if (p.drop_thresh) dpv = drop_keep(dkey, drow, (unsigned)key) ? dpv * p.drop_scale : 0.0f;     // d(P) through the dropout
+          sc[r] = pv * (dpv - dl);   // dS^T (without the softmax scale; folded into the final store)
         }
       }
 #pragma unroll
@@ -826,6 +850,8 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
   f32x16 dk[C::DT], dv[C::DT];
   zero_acc(dk);
   zero_acc(dv);
+  DropKey dkey{};
+  if (p.drop_thresh) dkey = drop_key(p.drop_seed, p.drop_site, p.drop_thresh);
 
   auto tile_step = [&](auto SL, int t) {             // unrolled by the ring depth: compile-time LDS slot (see attn_bwd_dq_kernel)
     constexpr int SLOT = decltype(SL)::value;
@@ -844,7 +870,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
     const char* gt = gimg(SLOT);
     const float* stl = stats + SLOT * 2 * TQ;
     const float* std_ = stl + TQ;
-    const bool boundary = (qb < full_vis_q) || (k0 + wave * 32 + 31 >= p.Nk);   // wave-uniform
+    const bool boundary = (qb < full_vis_q) || (k0 + wave * 32 + 31 >= p.Nk) || p.drop_thresh != 0;   // wave-uniform
     // phase 1: S = Q K^T and dP = dO V^T for both 32-row query sub-tiles (16 MFMAs back to back)
     f32x16 sc[2], dp[2];
 #pragma unroll
@@ -896,8 +922,15 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
             float pv = __builtin_amdgcn_exp2f(sc[u][r] * c + l4[j]);
             const int q = qb + 32 * u + acc_row(r, lh);
             if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : (dense ? (q < p.Nq && dense_vis(p, b, q, krow)) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos)))))) pv = 0.0f;
-            sc[u][r] = pv;
-            dp[u][r] = pv * (dp[u][r] + d4[j]);
+            float dpv = dp[u][r];
+            if (p.drop_thresh) {     // dV takes the dropped, rescaled P; dP comes back through the same mask
+              const bool keep = drop_keep(dkey, drop_row(dkey, (unsigned)((b * p.H + hd) * p.Nq + q)), (unsigned)krow);
+              dpv = keep ? dpv * p.drop_scale : 0.0f;
+              sc[u][r] = keep ? pv * p.drop_scale : 0.0f;
+            } else {
+              sc[u][r] = pv;
+            }
+            dp[u][r] = pv * (dpv + d4[j]);
           }
         }
       }
@@ -2248,6 +2281,18 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
   return FK_OK;
 }
 
+int set_dropout(const char* name, AttnArgs& a, float drop_p, const uint32_t* drop_seed, uint32_t drop_site, int flags) {
+  a.drop_seed = nullptr; a.drop_site = 0; a.drop_thresh = 0; a.drop_scale = 1.0f;
+  if (drop_p == 0.0f) return FK_OK;
+  FK_CHECK_ARG(drop_p > 0.0f && drop_p < 1.0f && drop_seed, "%s: dropout needs 0 <= p < 1 and the device seed words", name);
+  FK_CHECK_ARG(!(flags & FK_ATTN_Q_PRESCALED), "%s: dropout runs on the generic kernels (no FK_ATTN_Q_PRESCALED)", name);
+  FK_CHECK_ARG((int64_t)a.B * a.H * a.Nq < (1LL << 32), "%s: dropout rows are numbered with 32 bits", name);
+  const double t = (double)drop_p * 4294967296.0;
+  a.drop_seed = drop_seed; a.drop_site = drop_site; a.drop_scale = 1.0f / (1.0f - drop_p);
+  a.drop_thresh = t >= 4294967295.0 ? 4294967295u : (t < 1.0 ? 1u : (unsigned)t);
+  return FK_OK;
+}
+
 #define FK_ATTN_DISPATCH(FN, args, stream)                                                   \
   do {                                                                                        \
     if (dtype == FK_BF16) {                                                                   \
@@ -2281,10 +2326,11 @@ int fk_debug_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
-int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
-                int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
-                int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
-                const int32_t* limits, const int32_t* qfirst, float scale, int flags, int dtype, void* stream) {
+int fk_attn_fwd_dropout(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
+                        int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
+                        int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
+                        const int32_t* limits, const int32_t* qfirst, float scale, int flags, float drop_p, const uint32_t* drop_seed,
+                        uint32_t drop_site, int dtype, void* stream) {
   const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
   int rc = check_common("fk_attn_fwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
   if (rc) return rc;
@@ -2300,17 +2346,27 @@ int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
   FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_fwd: prefix / key-padding masks need both tables");
   FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (limits && !(flags & FK_ATTN_Q_PRESCALED)), "fk_attn_fwd: a dense mask needs its uint8 table in `limits` and the generic kernels (no FK_ATTN_Q_PRESCALED)");
   a.limits = limits; a.qfirst = qfirst; a.flags = flags;
+  rc = set_dropout("fk_attn_fwd", a, drop_p, drop_seed, drop_site, flags);
+  if (rc) return rc;
   FK_ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_fwd");
   return FK_OK;
 }
 
-int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-                void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
-                int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
-                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
-                const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int flags,
-                int dtype, void* stream) {
+int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
+                int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
+                int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
+                const int32_t* limits, const int32_t* qfirst, float scale, int flags, int dtype, void* stream) {
+  return fk_attn_fwd_dropout(Q, K, V, O, LSE, B, H, Nq, Nk, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, mask_kind, mask_c, q_off, k_off,
+                             limits, qfirst, scale, flags, 0.0f, nullptr, 0, dtype, stream);
+}
+
+int fk_attn_bwd_dropout(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                        void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
+                        int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
+                        int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
+                        const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int flags,
+                        float drop_p, const uint32_t* drop_seed, uint32_t drop_site, int dtype, void* stream) {
   const int64_t st[8] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs};
   int rc = check_common("fk_attn_bwd", B, H, Nq, Nk, D, dtype, mask_kind, mask_c, st, 8);
   if (rc) return rc;
@@ -2330,9 +2386,22 @@ int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
   FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_bwd: prefix / key-padding masks need both tables");
   FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (limits && !(flags & FK_ATTN_Q_PRESCALED)), "fk_attn_bwd: a dense mask needs its uint8 table in `limits` and the generic kernels (no FK_ATTN_Q_PRESCALED)");
   a.limits = limits; a.qfirst = qfirst; a.flags = flags;
+  rc = set_dropout("fk_attn_bwd", a, drop_p, drop_seed, drop_site, flags);
+  if (rc) return rc;
   FK_ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
   FK_CHECK_LAUNCH("fk_attn_bwd");
   return FK_OK;
+}
+
+int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
+                int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
+                int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
+                const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int flags,
+                int dtype, void* stream) {
+  return fk_attn_bwd_dropout(Q, K, V, O, dO, LSE, dQ, dK, dV, delta_ws, B, H, Nq, Nk, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
+                             mask_kind, mask_c, q_off, k_off, limits, qfirst, scale, rope_table, rope_bs, rope_off, flags, 0.0f, nullptr, 0,
+                             dtype, stream);
 }
 
 }  // extern "C"

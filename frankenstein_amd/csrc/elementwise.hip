@@ -141,6 +141,25 @@ __global__ void gelu_fwd_kernel(const T* x, T* y, int64_t nvec) {
     V16<T>::st(y + i * N, o);
   }
 }
+// y = [res +] keep(i) ? x * 1/(1-p) : 0     (nn.Dropout in training mode; the backward is the same kernel on dy without `res`)
+template <typename T>
+__global__ void dropout_kernel(const T* x, const T* res, T* y, int64_t nvec, const unsigned* seed, unsigned site, unsigned thresh, float ks) {
+  constexpr int N = V16<T>::N;
+  const DropKey key = drop_key(seed, site, thresh);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[N], o[N];
+    V16<T>::ld(x + i * N, a);
+    if (res) V16<T>::ld(res + i * N, o);
+    const int64_t e0 = i * N;
+    const unsigned row = drop_row(key, (unsigned)(e0 >> 32));       // N divides 2^32: the vector never straddles a change of the high word
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float v = drop_keep(key, row, (unsigned)e0 + j) ? a[j] * ks : 0.0f;
+      o[j] = res ? o[j] + v : v;
+    }
+    V16<T>::st(y + i * N, o);
+  }
+}
 template <typename T>
 __global__ void gelu_bwd_kernel(const T* x, const T* dy, T* dx, int64_t nvec) {
   constexpr int N = V16<T>::N;
@@ -438,6 +457,20 @@ int fk_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
   if (dtype == FK_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, dim3(grid_for(n / vec, 16384)), dim3(TPB), 0, s, (const bf16_t*)x, (bf16_t*)y, n / vec);
   else hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(grid_for(n / vec, 16384)), dim3(TPB), 0, s, (const float*)x, (float*)y, n / vec);
   FK_CHECK_LAUNCH("fk_gelu_fwd");
+  return FK_OK;
+}
+int fk_dropout(const void* x, const void* res, void* y, int64_t n, float p, const uint32_t* seed, uint32_t site, int dtype, void* stream) {
+  FK_DT_CHECK("fk_dropout");
+  const int vec = dtype == FK_BF16 ? 8 : 4;
+  FK_CHECK_ARG(x && y && seed && n > 0 && n % vec == 0, "fk_dropout: n must be a multiple of %d", vec);
+  FK_CHECK_ARG(p > 0.0f && p < 1.0f, "fk_dropout: p = %g outside (0, 1) (p = 0 is the caller's no-op)", (double)p);
+  const double t = (double)p * 4294967296.0;
+  const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (t < 1.0 ? 1u : (unsigned)t);
+  const float ks = 1.0f / (1.0f - p);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FK_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid_for(n / vec, 16384)), dim3(TPB), 0, s, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, n / vec, seed, site, thresh, ks);
+  else hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n / vec, 16384)), dim3(TPB), 0, s, (const float*)x, (const float*)res, (float*)y, n / vec, seed, site, thresh, ks);
+  FK_CHECK_LAUNCH("fk_dropout");
   return FK_OK;
 }
 int fk_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {

@@ -141,6 +141,24 @@ FK_DEV float wave_max(float v) {
   return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// dropout: a counter-based keep / drop decision per element (no mask is ever stored: the backward regenerates it).
+//   bits(hi, lo) = mix32(mix32(hi ^ seed) ^ (lo * 0x9E3779B9) ^ (step * 0x85EBCA6B + site)),   keep <=> bits >= p * 2^32
+// mix32 = the "lowbias32" integer finaliser.  seed / step live in DEVICE memory (seed_ptr[0..1]; the step word is advanced by the host
+// framework once per forward, inside a captured graph too), `site` numbers the dropout applications of one forward.  Elementwise: hi =
+// index >> 32, lo = index; attention probabilities: hi = (b * H + h) * Nq + q, lo = key.  This is the library's own stream, restated in
+// tests/dropout_ref.py; it does not reproduce torch's Philox stream (the reference's CPU and CUDA dropout streams differ from each other too).
+FK_DEV unsigned fk_mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+struct DropKey { unsigned seed, salt, thresh; };
+FK_DEV DropKey drop_key(const unsigned* seed_ptr, unsigned site, unsigned thresh) {
+  return DropKey{seed_ptr[0], seed_ptr[1] * 0x85EBCA6Bu + site, thresh};
+}
+FK_DEV unsigned drop_row(const DropKey& k, unsigned hi) { return fk_mix32(hi ^ k.seed) ^ k.salt; }
+FK_DEV bool drop_keep(const DropKey& k, unsigned row, unsigned lo) { return fk_mix32(row ^ (lo * 0x9E3779B9u)) >= k.thresh; }
+
 // XCD-aware block remap (bijective for any grid size): blocks b and b+8 share an XCD (round-robin
 // dispatch), so give each XCD a contiguous chunk of logical tile ids -> neighbouring tiles share L2.
 FK_DEV unsigned xcd_remap(unsigned bid, unsigned nwg) {

@@ -338,6 +338,57 @@ def _attn_prescale(D: int) -> bool:
     return _COMPUTE_DTYPE == torch.bfloat16 and D == 64 and os.environ.get("FK_ATTN_NO_PRESCALE") is None
 
 
+# --------------------------------------------------------------------------------------------- dropout
+# nn.Dropout / SDPA dropout_p of the GPT-2 decoder in training mode (models/gpt2_model.py:40,64,75,85,91,129).  No mask tensor exists:
+# every application is (p, seed words, site) and the kernels regenerate keep / drop from the element index (include/franken_hip.h,
+# fk_dropout).  The seed words live on the device — [torch.initial_seed(), a step counter advanced once per forward by dropout_begin()] —
+# so a captured training step draws new masks on every replay; `site` numbers the applications within one forward.
+_DROP_WORDS: dict = {}
+_DROP_SITE = [0]
+
+
+def dropout_words(device) -> Tensor:
+    device = torch.device(device)
+    seed = torch.initial_seed() & 0x7FFFFFFF
+    ent = _DROP_WORDS.get(device)
+    if ent is None or (ent[0] != seed and not torch.cuda.is_current_stream_capturing()):
+        ent = _DROP_WORDS[device] = (seed, torch.tensor([seed, 0], dtype=torch.int32, device=device))
+    return ent[1]
+
+
+def dropout_begin(device) -> None:
+    """Start of a training forward with dropout > 0: the next step's masks (step word + 1 on the device), sites numbered from 0."""
+    dropout_words(device)[1:].add_(1)
+    _DROP_SITE[0] = 0
+
+
+def dropout_site() -> int:
+    _DROP_SITE[0] += 1
+    return _DROP_SITE[0] - 1
+
+
+def drop_spec(p: float, device, n_sites: int):
+    """(p, seed words, site, ...) for one module call, or None when p == 0."""
+    if not p:
+        return None
+    assert 0.0 < p < 1.0, f"dropout p = {p}"
+    return (float(p), dropout_words(device)) + tuple(dropout_site() for _ in range(n_sites))
+
+
+class Dropout(torch.autograd.Function):
+    """y = nn.Dropout(p)(x) in training mode (embedding dropout, models/gpt2_model.py:129,190)."""
+
+    @staticmethod
+    def forward(ctx, x, drop):
+        ctx.drop = drop
+        return K.dropout(x.contiguous(), drop[0], drop[1], drop[2])
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = ctx.drop
+        return K.dropout(dy.contiguous(), d[0], d[1], d[2]), None
+
+
 # --------------------------------------------------------------------------------------------- functions
 class AttnBranch(torch.autograd.Function):
     """y = [x +] proj(SDPA(rope(q), rope(k), v)) with q,k,v = Linear([LN](x));  one pre-norm attention branch.
@@ -347,7 +398,8 @@ class AttnBranch(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, pw, pb, qkv_b, spec, *qkv_w):
-        H, D, mask, rope, residual, eps, nkind = spec
+        H, D, mask, rope, residual, eps, nkind = spec[:7]
+        drop = spec[7] if len(spec) > 7 else None       # (p, seed words, site of the attention dropout, site of the residual dropout)
         B, N, d = x.shape
         M = B * N
         x2 = x.view(M, d)
@@ -360,7 +412,7 @@ class AttnBranch(torch.autograd.Function):
         bq = None if qkv_b is None else shadow([qkv_b])
         prescale = False
         if rope is not None and D % 8 == 0 and (3 * HD) % 8 == 0:     # RoPE fused into the projection epilogue
-            prescale = _attn_prescale(D) and mask.kind != K.MASK_DENSE          # dense masks run on the generic kernels
+            prescale = _attn_prescale(D) and mask.kind != K.MASK_DENSE and drop is None     # dense masks / dropout: the generic kernels
             if prescale:
                 tab, qtab = rope.pair((1.0 / math.sqrt(D)) * 1.4426950408889634)
                 qkv = K.gemm_nt_rope(h, shadow(qkv_w), bq, tab, N, rope.pos_off(N), D, 2 * HD, q_cols=HD, q_table=qtab)
@@ -373,9 +425,13 @@ class AttnBranch(torch.autograd.Function):
             if rope is not None:
                 K.rope_(qkv3, 2 * H, D, rope.table, rope.pos_off(N))
         q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
-        o, lse = K.attn_fwd(q, k, v, mask, q_prescaled=prescale)
-        y = K.gemm_nt(o.view(M, HD), shadow([pw]), bias=None if pb is None else shadow([pb]),
-                      residual=x2 if residual else None)
+        o, lse = K.attn_fwd(q, k, v, mask, q_prescaled=prescale, dropout=None if drop is None else drop[:3])
+        if drop is None:
+            y = K.gemm_nt(o.view(M, HD), shadow([pw]), bias=None if pb is None else shadow([pb]),
+                          residual=x2 if residual else None)
+        else:                                           # x + resid_dropout(c_proj(y))  (models/gpt2_model.py:75,104)
+            y = K.gemm_nt(o.view(M, HD), shadow([pw]), bias=None if pb is None else shadow([pb]))
+            K.dropout(y, drop[0], drop[1], drop[3], residual=x2 if residual else None, out=y)
         ctx.spec, ctx.has_ln, ctx.nw, ctx.prescale = spec, has_ln, len(qkv_w), prescale
         ctx.flags = (ln_b is not None, pb is not None, qkv_b is not None)
         ctx.ln_b = ln_b
@@ -384,7 +440,8 @@ class AttnBranch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        H, D, mask, rope, residual, eps, nkind = ctx.spec
+        H, D, mask, rope, residual, eps, nkind = ctx.spec[:7]
+        drop = ctx.spec[7] if len(ctx.spec) > 7 else None
         sv = ctx.saved_tensors
         x, ln_w, pw = sv[0], sv[1], sv[2]
         qkv_w = sv[3:3 + ctx.nw]
@@ -396,18 +453,19 @@ class AttnBranch(torch.autograd.Function):
         if h is None:
             h = x2
         dy2 = dy.contiguous().view(M, -1)
-        do = K.gemm_nt(dy2, shadow([pw], transpose=True))
-        (dpw,) = wgrad(dy2, o.view(M, HD), [pw])
-        dpb = K.colsum(dy2) if has_pb else None
+        dyp = dy2 if drop is None else K.dropout(dy2, drop[0], drop[1], drop[3])        # the gradient behind the residual dropout
+        do = K.gemm_nt(dyp, shadow([pw], transpose=True))
+        (dpw,) = wgrad(dyp, o.view(M, HD), [pw])
+        dpb = K.colsum(dyp) if has_pb else None
         dqkv = torch.empty_like(qkv)
         qkv3, dqkv3 = qkv.view(B, N, 3 * HD), dqkv.view(B, N, 3 * HD)
         q, k, v = (qkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
         dq, dk, dv = (dqkv3[..., i * HD:(i + 1) * HD].unflatten(-1, (H, D)) for i in range(3))
         if rope is not None and D % 4 == 0:       # inverse RoPE fused into the dQ / dK stores
             K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask, rope_table=rope.table, rope_off=rope.pos_off(N),
-                       q_prescaled=ctx.prescale)
+                       q_prescaled=ctx.prescale, dropout=None if drop is None else drop[:3])
         else:
-            K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask)
+            K.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, dq, dk, dv, mask, dropout=None if drop is None else drop[:3])
             if rope is not None:
                 K.rope_(dqkv3, 2 * H, D, rope.table, rope.pos_off(N), conj=True)
         dh = K.gemm_nt(dqkv, shadow(qkv_w, transpose=True))
@@ -514,7 +572,8 @@ class MlpBranch(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, up_w, up_b, gate_w, down_w, down_b, spec):
-        residual, eps, nkind = spec
+        residual, eps, nkind = spec[:3]
+        drop = spec[3] if len(spec) > 3 else None       # (p, seed words, site): dropout on the down-projection's output
         shp = x.shape
         d = shp[-1]
         x2 = x.reshape(-1, d)
@@ -530,8 +589,12 @@ class MlpBranch(torch.autograd.Function):
             ups = [up_w] if gate_w is None else [up_w, gate_w]
             a = K.gemm_nt(h, shadow(ups), bias=None if up_b is None else shadow([up_b]))
             g = K.gelu_fwd(a) if gate_w is None else K.swiglu_fwd(a)
-        y = K.gemm_nt(g, shadow([down_w]), bias=None if down_b is None else shadow([down_b]),
-                      residual=x2 if residual else None)
+        if drop is None:
+            y = K.gemm_nt(g, shadow([down_w]), bias=None if down_b is None else shadow([down_b]),
+                          residual=x2 if residual else None)
+        else:                                           # x + dropout(c_proj(gelu(c_fc(x))))  (models/gpt2_model.py:87-92,105)
+            y = K.gemm_nt(g, shadow([down_w]), bias=None if down_b is None else shadow([down_b]))
+            K.dropout(y, drop[0], drop[1], drop[2], residual=x2 if residual else None, out=y)
         ctx.spec, ctx.has_ln, ctx.fused = spec, has_ln, fused
         ctx.flags = (ln_b is not None, up_b is not None, gate_w is not None, down_b is not None)
         ctx.ln_b = ln_b
@@ -540,7 +603,8 @@ class MlpBranch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        residual, eps, nkind = ctx.spec
+        residual, eps, nkind = ctx.spec[:3]
+        drop = ctx.spec[3] if len(ctx.spec) > 3 else None
         x, ln_w, up_w, gate_w, down_w, h, mean, rstd, a, g = ctx.saved_tensors
         has_lnb, has_ub, gated, has_db = ctx.flags
         shp = x.shape
@@ -550,14 +614,15 @@ class MlpBranch(torch.autograd.Function):
             h = x2
         dy2 = dy.contiguous().view(x2.shape[0], -1)
         ups = [up_w, gate_w] if gated else [up_w]
-        (ddown,) = wgrad(dy2, g, [down_w])
-        ddb = K.colsum(dy2) if has_db else None
+        dyd = dy2 if drop is None else K.dropout(dy2, drop[0], drop[1], drop[2])         # the gradient behind the dropout
+        (ddown,) = wgrad(dyd, g, [down_w])
+        ddb = K.colsum(dyd) if has_db else None
         if ctx.fused:   # down-projection dgrad + SwiGLU backward in one kernel; dg is never materialised
-            da = K.gemm_nt_dswiglu(dy2, shadow([down_w], transpose=True), a)
+            da = K.gemm_nt_dswiglu(dyd, shadow([down_w], transpose=True), a)
             dh = K.gemm_nt(da, shadow_swiglu(up_w, gate_w, transpose=True))
             dups = wgrad(da, h, [up_w, gate_w], swiglu_interleaved=True)
         else:
-            dg_ = K.gemm_nt(dy2, shadow([down_w], transpose=True))
+            dg_ = K.gemm_nt(dyd, shadow([down_w], transpose=True))
             da = K.swiglu_bwd(a, dg_) if gated else K.gelu_bwd(a, dg_)
             dh = K.gemm_nt(da, shadow(ups, transpose=True))
             dups = wgrad(da, h, ups)

@@ -228,9 +228,10 @@ def _bnhd(t: Tensor):
 
 
 def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optional[float] = None,
-             out: Optional[Tensor] = None, q_prescaled: bool = False) -> Tuple[Tensor, Tensor]:
+             out: Optional[Tensor] = None, q_prescaled: bool = False, dropout: Optional[tuple] = None) -> Tuple[Tensor, Tensor]:
     """q [B,Nq,H,D], k/v [B,Nk,H,D] (strided views ok) -> (o [B,Nq,H,D], lse [B,H,Nq] fp32).
-    q_prescaled: q already holds scale * log2(e) * q (gemm_nt_rope's q_table; bf16, D = 64 only)."""
+    q_prescaled: q already holds scale * log2(e) * q (gemm_nt_rope's q_table; bf16, D = 64 only).
+    dropout = (p, seed words [2] int32 on the device, site): SDPA's dropout_p in training mode (fk_attn_fwd_dropout)."""
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     assert k.shape == (B, Nk, H, D) and v.shape == (B, Nk, H, D) and q.dtype == k.dtype == v.dtype
@@ -240,16 +241,22 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optio
     (qb, qr), (kb, kr), (vb, vr), (ob, orr) = _bnhd(q), _bnhd(k), _bnhd(v), _bnhd(out)
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
     with _timed(f"attn_fwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
-      call("fk_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
-           qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst),
-           sc, ATTN_Q_PRESCALED if q_prescaled else 0, fk_dtype(q), _stream())
+      if dropout is None:
+        call("fk_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
+             qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst),
+             sc, ATTN_Q_PRESCALED if q_prescaled else 0, fk_dtype(q), _stream())
+      else:
+        call("fk_attn_fwd_dropout", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
+             qb, qr, kb, kr, vb, vr, ob, orr, mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst),
+             sc, ATTN_Q_PRESCALED if q_prescaled else 0, dropout[0], dropout[1].data_ptr(), dropout[2], fk_dtype(q), _stream())
     return out, lse
 
 
 def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
              mask: Mask = NO_MASK, scale: Optional[float] = None, rope_table: Optional[Tensor] = None,
-             rope_off: int = 0, q_prescaled: bool = False) -> None:
-    """Writes dq/dk/dv (same strides as q/k/v); do must have o's strides.  rope_table: also un-rotate dq/dk (RoPE backward)."""
+             rope_off: int = 0, q_prescaled: bool = False, dropout: Optional[tuple] = None) -> None:
+    """Writes dq/dk/dv (same strides as q/k/v); do must have o's strides.  rope_table: also un-rotate dq/dk (RoPE backward).
+    dropout: the forward's (p, seed words, site) — the mask is regenerated, not stored."""
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     (qb, qr), (kb, kr), (vb, vr), (ob, orr) = _bnhd(q), _bnhd(k), _bnhd(v), _bnhd(o)
@@ -258,11 +265,15 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     delta = torch.empty(2 * B * H * ((Nq + 63) // 64 * 64), dtype=torch.float32, device=q.device)     # scratch: row statistics for dK/dV
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
     with _timed(f"attn_bwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):
-      call("fk_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
-           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
-           mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst), sc, _ptr(rope_table),
-           0 if rope_table is None or rope_table.dim() == 3 else rope_table.stride(0), rope_off,
-           ATTN_Q_PRESCALED if q_prescaled else 0, fk_dtype(q), _stream())
+      head = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
+              mask.kind, mask.c, mask.q_off, mask.k_off, _ptr(mask.limits), _ptr(mask.qfirst), sc, _ptr(rope_table),
+              0 if rope_table is None or rope_table.dim() == 3 else rope_table.stride(0), rope_off,
+              ATTN_Q_PRESCALED if q_prescaled else 0)
+      if dropout is None:
+        call("fk_attn_bwd", *head, fk_dtype(q), _stream())
+      else:
+        call("fk_attn_bwd_dropout", *head, dropout[0], dropout[1].data_ptr(), dropout[2], fk_dtype(q), _stream())
 
 
 def attn_combine(parts: Tensor, lse_parts: Optional[Tensor] = None, want_lse: bool = True):
@@ -362,6 +373,16 @@ def gelu_fwd(x: Tensor) -> Tensor:
     assert x.is_contiguous()
     y = torch.empty_like(x)
     call("fk_gelu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), fk_dtype(x), _stream())
+    return y
+
+
+def dropout(x: Tensor, p: float, seed: Tensor, site: int, residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """y = [residual +] keep ? x / (1 - p) : 0 (fk_dropout; nn.Dropout in training mode).  seed: int32 [2] on the device (seed, step).
+    The backward is the same call on dy (same p / seed / site) without residual."""
+    assert x.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype))
+    assert seed.dtype == torch.int32 and seed.numel() == 2 and seed.device == x.device
+    y = torch.empty_like(x) if out is None else out
+    call("fk_dropout", x.data_ptr(), _ptr(residual), y.data_ptr(), x.numel(), p, seed.data_ptr(), site, fk_dtype(x), _stream())
     return y
 
 

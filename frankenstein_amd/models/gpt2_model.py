@@ -47,9 +47,9 @@ class CausalSelfAttention(nn.Module):
         self.dropout = config.dropout
 
     def branch(self, x, ln, residual: bool):
-        if self.dropout and self.training:
-            raise NotImplementedError("attention/residual dropout > 0 is not implemented in the fused kernels")
         spec = (self.n_head, self.n_embd // self.n_head, CAUSAL, None, residual, 0.0 if ln is None else ln.eps, K.NORM_LAYER)
+        if self.dropout and self.training:          # SDPA dropout_p + resid_dropout (models/gpt2_model.py:64,75): two sites
+            spec = spec + (E.drop_spec(self.dropout, x.device, 2),)
         return E.AttnBranch.apply(x, None if ln is None else ln.weight, None if ln is None else ln.bias,
                                   self.c_proj.weight, self.c_proj.bias, self.c_attn.bias, spec, self.c_attn.weight)
 
@@ -66,11 +66,11 @@ class MLP(nn.Module):
         self.dropout = nn.Dropout(config.dropout)
 
     def branch(self, x, ln, residual: bool):
-        if self.dropout.p and self.training:
-            raise NotImplementedError("MLP dropout > 0 is not implemented in the fused kernels")
+        spec = (residual, 0.0 if ln is None else ln.eps, K.NORM_LAYER)
+        if self.dropout.p and self.training:        # models/gpt2_model.py:91
+            spec = spec + (E.drop_spec(self.dropout.p, x.device, 1),)
         return E.MlpBranch.apply(x, None if ln is None else ln.weight, None if ln is None else ln.bias,
-                                 self.c_fc.weight, self.c_fc.bias, None, self.c_proj.weight, self.c_proj.bias,
-                                 (residual, 0.0 if ln is None else ln.eps, K.NORM_LAYER))
+                                 self.c_fc.weight, self.c_fc.bias, None, self.c_proj.weight, self.c_proj.bias, spec)
 
     def forward(self, x):
         return self.branch(_prep(x), None, False)
@@ -219,11 +219,14 @@ class GPT(nn.Module):
 
     def forward(self, idx, prefix=None, targets=None):
         t_words = idx.size(1)
-        if self.config.dropout and self.training:
-            raise NotImplementedError("embedding dropout > 0 is not implemented in the fused kernels")
+        dropping = bool(self.transformer.drop.p) and self.training
+        if dropping:
+            E.dropout_begin(idx.device)               # this forward's masks: step word + 1, sites from 0
         if prefix is not None:
             prefix = _prep(prefix)
         x = _GptEmbed.apply(idx, prefix, self.transformer.wte.weight, self.transformer.wpe.weight)
+        if dropping:                                  # transformer.drop(tok_emb + pos_emb), models/gpt2_model.py:190
+            x = E.Dropout.apply(x, E.drop_spec(self.transformer.drop.p, x.device, 1))
         for block in self.transformer.h:
             x = block(x)
         x = _prep(x[:, -t_words:])            # keep only the text positions (strided-copy kernel)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FK_VERSION 300
+#define FK_VERSION 301
 
 #define FK_OK 0
 #define FK_EINVAL (-1)       /* bad shape / dtype / alignment / null pointer */
@@ -88,9 +88,15 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
  * KEYPAD (padding mask of models/simple_mae:228-236,349-352): visible(q,k) = limits[b,q] != 0 && qfirst[b,k] != 0, i.e. the two
  * int32 tables are the query / key validity flags.  DENSE (any boolean mask: models/brainformer.py:160-168 passes whatever it is given):
  * `limits` points to uint8 [Bm, Nq, Nk] (non-zero = attend; heads share it), mask_c = its batch stride in elements (0: one mask for every
- * sample), qfirst unused; every tile takes the per-element path of the generic kernels (FK_ATTN_Q_PRESCALED is refused).  Fully masked rows give 0.  D in {16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share
- * Q/K/V's strides; delta_ws is fp32 scratch of 2 * B * H * roundup(Nq, 64) floats (the row statistics the dQ kernel hands to the dK/dV kernel).  rope_table != NULL (self-attention only) additionally applies the
- * inverse RoPE (rotation by -angle at position rope_off + index) to dQ and dK as they are stored = apply_rope's backward.                                                        */
+ * sample), qfirst unused; every tile takes the per-element path of the generic kernels (FK_ATTN_Q_PRESCALED is refused).
+ * Fully masked rows give 0.  D in {8,16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share Q/K/V's strides; delta_ws
+ * is fp32 scratch of 2 * B * H * roundup(Nq, 64) floats (the row statistics the dQ kernel hands to the dK/dV kernel).  rope_table != NULL
+ * (self-attention only) additionally applies the inverse RoPE (rotation by -angle at position rope_off + index) to dQ and dK as they are
+ * stored = apply_rope's backward.
+ * *_dropout: the same with dropout on the attention probabilities (F.scaled_dot_product_attention(dropout_p=...) in training mode,
+ * models/gpt2_model.py:64): softmax over all visible keys, then entries dropped with probability drop_p and the kept ones scaled by
+ * 1 / (1 - drop_p).  No mask is stored: forward and backward regenerate it from (drop_seed[0..1] in DEVICE memory, drop_site, b, h, q, k)
+ * — see fk_dropout.  drop_p == 0: identical to the plain entry points.  Generic kernels only (FK_ATTN_Q_PRESCALED is refused).            */
 int fk_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
                 int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
                 int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
@@ -101,6 +107,28 @@ int fk_attn_bwd(const void* Q, const void* K, const void* V, const void* O, cons
                 int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
                 const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int flags,
                 int dtype, void* stream);
+
+int fk_attn_fwd_dropout(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t H, int64_t Nq,
+                        int64_t Nk, int64_t D, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
+                        int64_t v_rs, int64_t o_bs, int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off,
+                        const int32_t* limits, const int32_t* qfirst, float scale, int flags, float drop_p, const uint32_t* drop_seed,
+                        uint32_t drop_site, int dtype, void* stream);
+int fk_attn_bwd_dropout(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                        void* dQ, void* dK, void* dV, float* delta_ws, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
+                        int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
+                        int64_t o_rs, int mask_kind, int64_t mask_c, int64_t q_off, int64_t k_off, const int32_t* limits,
+                        const int32_t* qfirst, float scale, const float* rope_table, int64_t rope_bs, int64_t rope_off, int flags,
+                        float drop_p, const uint32_t* drop_seed, uint32_t drop_site, int dtype, void* stream);
+
+/* ---- dropout (nn.Dropout in training mode: models/gpt2_model.py:40,75 resid_dropout, :85,91 MLP, :129 embeddings).
+ *      y[i] = (res ? res[i] : 0) + (keep(i) ? x[i] / (1 - p) : 0), n contiguous elements (multiple of 16 bytes), y may alias x.  The backward
+ *      is the same call on dy without res.  keep(i) is a counter-based decision, nothing is stored:
+ *        bits = mix32(mix32(hi ^ seed[0]) ^ (lo * 0x9E3779B9) ^ (seed[1] * 0x85EBCA6B + site)),  keep <=> bits >= p * 2^32,
+ *      mix32 = lowbias32 (x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16), (hi, lo) = the two words of i (for
+ *      attention probabilities: hi = (b * H + h) * Nq + q, lo = k).  seed[0] = the run's seed, seed[1] = a step counter the caller advances
+ *      once per forward — both read from DEVICE memory so that a captured graph draws a new mask on every replay; `site` numbers the
+ *      dropout applications within one forward.  The stream is the library's own (torch's CPU and CUDA dropout streams differ too).     */
+int fk_dropout(const void* x, const void* res, void* y, int64_t n, float p, const uint32_t* seed, uint32_t site, int dtype, void* stream);
 
 /* ---- normalisation (nn.LayerNorm: models/brainformer.py:237,239,252,254,287,500; F.layer_norm models/gpt2_model.py:27;
  *      RMSNorm models/brainformer.py:221-232).  x,y [rows, dim] contiguous; gamma/beta fp32 (beta may be NULL);

@@ -231,8 +231,18 @@ def brainformer_ce(sd, x: Tensor, targets: Optional[Tensor], cfg):
 
 
 # --------------------------------------------------------------------------- GPT-2
-def gpt_attention(sd, p: str, x: Tensor, n_head: int) -> Tensor:
-    """models/gpt2_model.py:52-76 (fused c_attn, causal, dropout 0)."""
+def sdpa_dropout(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], keep_scaled: Tensor) -> Tensor:
+    """F.scaled_dot_product_attention(..., dropout_p=p) in training mode (models/gpt2_model.py:64) with the draw given: the softmax over
+    the visible keys, then keep_scaled = keep / (1 - p) applied to the probabilities ([B, H, T, T])."""
+    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    return (torch.softmax(s, dim=-1) * keep_scaled) @ v
+
+
+def gpt_attention(sd, p: str, x: Tensor, n_head: int, masks=None) -> Tensor:
+    """models/gpt2_model.py:52-76 (fused c_attn, causal).  masks: None (dropout 0 / eval) or an iterator of keep / (1 - p) tensors, one
+    per dropout application in call order (attention probabilities :64, resid_dropout :75)."""
     B, T, C = x.shape
     qkv = linear(x, sd[p + "c_attn.weight"], sd.get(p + "c_attn.bias"))
     q, k, v = qkv.split(C, dim=2)
@@ -241,22 +251,28 @@ def gpt_attention(sd, p: str, x: Tensor, n_head: int) -> Tensor:
     k = k.view(B, T, n_head, hs).transpose(1, 2)
     v = v.view(B, T, n_head, hs).transpose(1, 2)
     causal = torch.ones(T, T, dtype=torch.bool).tril()
-    y = sdpa(q, k, v, causal).transpose(1, 2).reshape(B, T, C)
-    return linear(y, sd[p + "c_proj.weight"], sd.get(p + "c_proj.bias"))
+    if masks is None:
+        y = sdpa(q, k, v, causal).transpose(1, 2).reshape(B, T, C)
+        return linear(y, sd[p + "c_proj.weight"], sd.get(p + "c_proj.bias"))
+    y = sdpa_dropout(q, k, v, causal, next(masks)).transpose(1, 2).reshape(B, T, C)
+    return linear(y, sd[p + "c_proj.weight"], sd.get(p + "c_proj.bias")) * next(masks)
 
 
-def gpt_block(sd, p: str, x: Tensor, n_head: int) -> Tensor:
-    """models/gpt2_model.py:103-106, 87-92."""
+def gpt_block(sd, p: str, x: Tensor, n_head: int, masks=None) -> Tensor:
+    """models/gpt2_model.py:103-106, 87-92 (MLP dropout :91 when masks are given)."""
     h = layer_norm(x, sd[p + "ln_1.weight"], sd.get(p + "ln_1.bias"))
-    x = x + gpt_attention(sd, p + "attn.", h, n_head)
+    x = x + gpt_attention(sd, p + "attn.", h, n_head, masks)
     h = layer_norm(x, sd[p + "ln_2.weight"], sd.get(p + "ln_2.bias"))
     h = gelu_erf(linear(h, sd[p + "mlp.c_fc.weight"], sd.get(p + "mlp.c_fc.bias")))
-    return x + linear(h, sd[p + "mlp.c_proj.weight"], sd.get(p + "mlp.c_proj.bias"))
+    h = linear(h, sd[p + "mlp.c_proj.weight"], sd.get(p + "mlp.c_proj.bias"))
+    return x + (h if masks is None else h * next(masks))
 
 
 def gpt_forward(sd, idx: Tensor, prefix: Optional[Tensor], targets: Optional[Tensor], cfg,
-                p: str = ""):
-    """models/gpt2_model.py:178-216.  lm_head weight is tied to wte (:138)."""
+                p: str = "", masks=None):
+    """models/gpt2_model.py:178-216.  lm_head weight is tied to wte (:138).  masks: training mode with dropout > 0 — an iterator of
+    keep / (1 - p) tensors in the order the reference applies its dropouts (transformer.drop :190, then per block the attention
+    probabilities :64, resid_dropout :75, the MLP's :91)."""
     wte = sd[p + "transformer.wte.weight"]
     t_words = idx.shape[1]
     tok = wte[idx]
@@ -264,8 +280,10 @@ def gpt_forward(sd, idx: Tensor, prefix: Optional[Tensor], targets: Optional[Ten
         tok = torch.cat([prefix, tok], dim=1)
     t_full = tok.shape[1]
     x = tok + sd[p + "transformer.wpe.weight"][:t_full]
+    if masks is not None:
+        x = x * next(masks)
     for i in range(cfg.n_layer):
-        x = gpt_block(sd, f"{p}transformer.h.{i}.", x, cfg.n_head)
+        x = gpt_block(sd, f"{p}transformer.h.{i}.", x, cfg.n_head, masks)
     x = x[:, -t_words:]
     x = layer_norm(x, sd[p + "transformer.ln_f.weight"], sd.get(p + "transformer.ln_f.bias"))
     if targets is not None:

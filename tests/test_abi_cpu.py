@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_symbol(built):
     for s in declared_symbols():
         assert hasattr(h, s), f"{s} declared in include/franken_hip.h but not exported"
     lib = _lib.lib()
-    assert lib.fk_version() == 300
+    assert lib.fk_version() == 301
     assert lib.fk_last_error() is not None
 
 

@@ -708,6 +708,74 @@ def test_attention_dense_mask_agrees_with_the_analytic_kinds(K):
         K.attn_fwd(qv.bfloat16().repeat(1, 1, 1, 2), kv.bfloat16().repeat(1, 1, 1, 2), vv.bfloat16().repeat(1, 1, 1, 2), m, q_prescaled=True)
 
 
+# ----------------------------------------------------------------------------------------------- dropout
+def drop_words(seed, step):
+    return torch.tensor([seed, step], dtype=torch.int32, device="cuda")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_elementwise_is_the_documented_stream(K, dtype, p):
+    """fk_dropout = nn.Dropout in training mode (models/gpt2_model.py:75,91,190): every keep / drop decision equals the host restatement
+    (tests/dropout_ref.py), kept values are x / (1 - p), the residual form adds, and the backward is the same mask."""
+    from tests import dropout_ref as DR
+    n, seed, step, site = 3 * 1000 * 64, 1234567, 5, 3
+    x = rnd(n, seed=1) + 3.0                                              # no zeros: a zero output is a dropped element
+    words = drop_words(seed, step)
+    y = K.dropout(dev(x, dtype), p, words, site)
+    keep = torch.from_numpy(DR.keep_flat(seed, step, site, n, p))
+    assert torch.equal(y.cpu() != 0, keep)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 4.0 * math.sqrt(p * (1 - p) / n)
+    want = torch.where(keep, q(x, dtype) * (1.0 / (1.0 - float(np.float32(p)))), torch.zeros(()))
+    close(y, want, dtype, atol32=1e-6, rtol32=1e-6, atol16=0.0, rtol16=8e-3)
+    res = rnd(n, seed=2)
+    y2 = K.dropout(dev(x, dtype), p, words, site, residual=dev(res, dtype))
+    close(y2, want + q(res, dtype), dtype, atol32=1e-6, rtol32=1e-6, atol16=4e-2, rtol16=8e-3)
+    # another site, another step, another seed: other masks
+    for w, st_ in ((words, site + 1), (drop_words(seed, step + 1), site), (drop_words(seed + 1, step), site)):
+        other = K.dropout(dev(x, dtype), p, w, st_).cpu() != 0
+        assert 0.2 * min(p, 1 - p) < float((other != keep).float().mean()) < 2.2 * p * (1 - p) + 0.05
+    from frankenstein_amd._lib import FrankenHipError
+    with pytest.raises(FrankenHipError, match="outside"):
+        K.dropout(dev(x, dtype), 1.0, words, site)
+
+
+ATTN_DROP_CASES = [
+    # B, H, Nq, Nk, D, mask kind, c, p
+    (2, 2, 200, 200, 64, 1, 0, 0.1),
+    (1, 3, 57, 300, 32, 0, 0, 0.5),
+    (2, 2, 128, 128, 16, 2, 16, 0.25),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", ATTN_DROP_CASES)
+def test_attention_dropout_matches_the_oracle_with_the_same_draw(K, dtype, case):
+    """fk_attn_*_dropout = SDPA(dropout_p) in training mode (models/gpt2_model.py:64): with the mask predicted on the host, forward and
+    all three gradients equal the oracle's softmax -> dropout -> P V."""
+    from tests import dropout_ref as DR
+    B, H, Nq, Nk, D, kind, c, p = case
+    seed, step, site = 424242, 9, 2
+    words = drop_words(seed, step)
+    keep = torch.from_numpy(DR.keep_attention(seed, step, site, B, H, Nq, Nk, p))
+    ks = keep.float() * (1.0 / (1.0 - float(np.float32(p))))
+    qv, kv, vv, do = rnd(B, Nq, H, D, seed=1), rnd(B, Nk, H, D, seed=2), rnd(B, Nk, H, D, seed=3), rnd(B, Nq, H, D, seed=4)
+    qd, kd, vd = dev(qv, dtype), dev(kv, dtype), dev(vv, dtype)
+    m = K.Mask(kind, c)
+    o, lse = K.attn_fwd(qd, kd, vd, m, dropout=(p, words, site))
+    qr, kr, vr = (q(t_, dtype).requires_grad_(True) for t_ in (qv, kv, vv))
+    oref = R.sdpa_dropout(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), mask_tensor(kind, c, Nq, Nk), ks).transpose(1, 2)
+    close(o, oref, dtype, atol32=2e-5, atol16=3e-2)
+    o0, lse0 = K.attn_fwd(qd, kd, vd, m)
+    assert torch.equal(lse, lse0)                                         # the softmax statistics do not see the dropout
+    oref.backward(q(do, dtype))
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    K.attn_bwd(qd, kd, vd, o, dev(do, dtype), lse, dq, dk, dv, m, dropout=(p, words, site))
+    close(dq, qr.grad, dtype, atol32=5e-5, atol16=5e-2)
+    close(dk, kr.grad, dtype, atol32=5e-5, atol16=5e-2)
+    close(dv, vr.grad, dtype, atol32=5e-5, atol16=5e-2)
+
+
 def test_shadow_refresh_single_launch(K):
     """fk_cast_pack_multi (engine.refresh_shadows): every weight shadow re-packed in one launch == the per-weight packs."""
     import frankenstein_amd as fa

@@ -46,10 +46,10 @@ def mk_bf(cfgo, cls):
     return load_synth(cls(cfg))
 
 
-def mk_gpt(cfgo):
+def mk_gpt(cfgo, dropout=0.0):
     from frankenstein_amd.models import gpt2_model as g2
     return g2.GPT(g2.GPTConfig(block_size=cfgo.block_size, vocab_size=cfgo.vocab_size, n_layer=cfgo.n_layer,
-                               n_head=cfgo.n_head, n_embd=cfgo.n_embd, dropout=0.0, bias=cfgo.bias))
+                               n_head=cfgo.n_head, n_embd=cfgo.n_embd, dropout=dropout, bias=cfgo.bias))
 
 
 def named_grads(model):
@@ -121,6 +121,107 @@ def test_gpt_small_fp32(golden, bias):
     loss2, logits2 = g(idx.cuda(), prefix=None, targets=tk.cuda())
     assert abs(float(loss2) - float(z["loss_noprefix"])) < 1e-5
     np.testing.assert_allclose(logits2.float().cpu().detach().numpy(), z["logits_noprefix"], atol=1e-4)
+
+
+def _gpt_drop_masks(cfgo, seed, step, B, T, p):
+    """keep / (1 - p) tensors in the reference's order of application (oracle gpt_forward): embeddings, then per block the attention
+    probabilities, resid_dropout, the MLP — sites 0, 1, 2, ... of one forward."""
+    from tests import dropout_ref as DR
+    ks = 1.0 / (1.0 - float(np.float32(p)))
+    d, H = cfgo.n_embd, cfgo.n_head
+    out, site = [], 0
+
+    def flat():
+        nonlocal site
+        out.append(torch.from_numpy(DR.keep_flat(seed, step, site, B * T * d, p)).view(B, T, d).float() * ks)
+        site += 1
+
+    flat()
+    for _ in range(cfgo.n_layer):
+        out.append(torch.from_numpy(DR.keep_attention(seed, step, site, B, H, T, T, p)).float() * ks)
+        site += 1
+        flat()
+        flat()
+    return out
+
+
+@pytest.mark.parametrize("bias", [True, False])
+def test_gpt_dropout_training_step_matches_the_oracle_with_the_same_draws(bias):
+    """config.dropout > 0 in training mode (models/gpt2_model.py:40,64,75,85,91,190): loss, logits and every gradient against the
+    oracle's forward with the library's draws predicted on the host; eval mode ignores dropout; a second forward draws again."""
+    from frankenstein_amd import engine as E
+    p, seed = 0.2, 20240607
+    torch.manual_seed(seed)
+    cfgo, prefix, tk, idx = C.gpt_small(bias)
+    g = load_synth(mk_gpt(cfgo, dropout=p))
+    sd = {k: v.clone().requires_grad_(True) for k, v in C.state(R.gpt_shapes(cfgo)).items()}
+    B, T = idx.shape[0], idx.shape[1] + prefix.shape[1]
+    g.train()
+    words = E.dropout_words(torch.device("cuda", torch.cuda.current_device()))
+    step0 = int(words[1])
+    pf = prefix.cuda().requires_grad_(True)
+    loss, logits = g(idx.cuda(), prefix=pf, targets=tk.cuda())
+    assert int(words[0]) == seed & 0x7FFFFFFF and int(words[1]) == step0 + 1
+    pr = prefix.clone().requires_grad_(True)
+    rl, rlog = R.gpt_forward(sd, idx, pr, tk, cfgo, masks=iter(_gpt_drop_masks(cfgo, seed, step0 + 1, B, T, p)))
+    assert abs(float(loss) - float(rl)) < 2e-5
+    torch.testing.assert_close(logits.float().cpu(), rlog, atol=2e-4, rtol=1e-4)
+    loss.backward()
+    rl.backward()
+    torch.testing.assert_close(pf.grad.cpu(), pr.grad, rtol=1e-3, atol=1e-6)
+    got = named_grads(g)
+    for k, v in sd.items():
+        if not k.endswith("lm_head.weight"):
+            torch.testing.assert_close(got[k], v.grad if v.grad is not None else torch.zeros_like(v), rtol=1e-3, atol=2e-5, msg=k)
+    # a second training forward draws new masks (the step word moved on) ...
+    loss2, _ = g(idx.cuda(), prefix=prefix.cuda(), targets=tk.cuda())
+    rl2, _ = R.gpt_forward(sd, idx, prefix, tk, cfgo, masks=iter(_gpt_drop_masks(cfgo, seed, step0 + 2, B, T, p)))
+    assert abs(float(loss2) - float(rl2)) < 2e-5 and abs(float(loss2) - float(loss)) > 1e-4
+    # ... and eval mode is the dropout-free forward
+    g.eval()
+    le, _ = g(idx.cuda(), prefix=prefix.cuda(), targets=tk.cuda())
+    r0, _ = R.gpt_forward(sd, idx, prefix, tk, cfgo)
+    assert abs(float(le) - float(r0)) < 1e-5 and int(words[1]) == step0 + 2
+
+
+def test_gpt_dropout_in_a_captured_graph_draws_new_masks_per_replay():
+    """The seed words are read from device memory: a hipGraph of forward + backward gives a different draw on every replay, and each
+    replay equals the eager step with the same step word."""
+    from frankenstein_amd import engine as E
+    fa.set_compute_dtype("fp32")
+    cfgo, prefix, tk, idx = C.gpt_small(True)
+    g = load_synth(mk_gpt(cfgo, dropout=0.3))
+    g.train()
+    args = (idx.cuda(), prefix.cuda(), tk.cuda())
+
+    def fwd_bwd():
+        loss, _ = g(args[0], prefix=args[1], targets=args[2])
+        loss.backward()
+        return loss.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            g.zero_grad(set_to_none=True)
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    g.zero_grad(set_to_none=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fwd_bwd()
+    words = E.dropout_words(torch.device("cuda", torch.cuda.current_device()))
+    losses = []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        losses.append((int(words[1]), float(out)))
+    assert len({round(l, 7) for _, l in losses}) == 3, losses
+    assert [s_ for s_, _ in losses] == [losses[0][0], losses[0][0] + 1, losses[0][0] + 2]
+    # eager forward with the step word set back: the same draw as the replay that used it
+    words[1] = losses[1][0] - 1
+    g.zero_grad(set_to_none=True)
+    assert abs(float(fwd_bwd()) - losses[1][1]) < 1e-6
 
 
 @pytest.mark.parametrize("use_cache", [True, False], ids=["kv-cache", "re-forward"])
