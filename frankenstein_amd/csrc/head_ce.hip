@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void head_ce_kernel(HeadCeArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += __expf(v[j][r] - ref);
       sum += __shfl_xor(sum, 32, 64);
-      if (m_ok && lh == 0) {
+      if (m_ok && lh == 0 && part < p.npart) {      // (the tile's second column half may lie wholly past the last part: V = 129 has 3 parts, 2 tiles)
         p.pmax[(int64_t)m * p.npart + part] = mx;
         p.psum[(int64_t)m * p.npart + part] = sum;
       }

@@ -923,7 +923,7 @@ def test_sample_topk_on_device(K):
 
 # ----------------------------------------------------------------------------------------------- fused head + cross entropy
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("rows,V,Kd,bias", [(203, 211, 64, True), (130, 1000, 96, False), (64, 129, 32, True)])
+@pytest.mark.parametrize("rows,V,Kd,bias", [(203, 211, 64, True), (130, 1000, 96, False), (64, 129, 32, True), (333, 300, 32, False)])   # 129, 300: an odd number of 64-column parts
 def test_head_ce_fused_kernels(K, dtype, rows, V, Kd, bias):
     """fk_head_ce_fwd / fk_head_ce_bwd (lm_head + F.cross_entropy, models/gpt2_model.py:205-210, without the logits) against torch on the
     same rounded operands: loss, row log-sum-exp, the transposed d-logits (padding rows / columns zero) and the bias gradient; ragged
