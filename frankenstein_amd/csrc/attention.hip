@@ -1543,6 +1543,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_asm_kernel(AttnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // stray requests landed, the last MFMAs retired
     if (!lean_ok) break;
+#ifdef FK_FWD_PROBE_NOREDO
+    break;                                                       // timing builds of ablated streams (tools/stream_variants.sh): their sums mean nothing
+#endif
     // 3. did any wave of the workgroup see a half-row sum outside the safe range?  (rare: then everything again, classic only)
     const bool trip = __builtin_amdgcn_ballot_w64(!(rmax <= PS_REDO)) != 0;
     if (tid == 0) *flag = 0;
