@@ -22,3 +22,20 @@ def golden():
         return np.load(ROOT / "tests" / "golden" / f"{name}.npz", allow_pickle=False)
 
     return load
+
+
+@pytest.fixture(scope="session")
+def _poison_tracker():
+    """FK_TEST_POISON=1: guard bands around and NaN fill inside every buffer the product allocates (tests/poison.py)"""
+    if os.environ.get("FK_TEST_POISON") != "1":
+        return None
+    from tests import poison
+    return poison.install()
+
+
+@pytest.fixture(autouse=True)
+def _poison_check(request, _poison_tracker):
+    yield
+    if _poison_tracker is not None:
+        bad = _poison_tracker.check()
+        assert not bad, f"a kernel wrote outside its buffer (allocation index, bytes, side): {bad}"

@@ -776,6 +776,30 @@ def test_attention_dropout_matches_the_oracle_with_the_same_draw(K, dtype, case)
     close(dv, vr.grad, dtype, atol32=5e-5, atol16=5e-2)
 
 
+def test_poison_allocator_sees_overruns_and_unwritten_outputs(K):
+    """tests/poison.py (FK_TEST_POISON=1 runs the whole suite under it): its guard bands catch a write one element past a buffer, its
+    fill makes an unwritten output NaN; and when the mode is on, the product's allocations really go through it."""
+    import os
+    from tests import poison
+    t = poison.Tracker()
+    x = t.alloc((10,), torch.float32, "cuda", poison=True, fallback=None)
+    assert bool(torch.isnan(x).all())
+    x.fill_(1.0)
+    assert t.check() == []
+    y = t.alloc((3, 8), torch.bfloat16, "cuda", poison=False, fallback=None)
+    assert float(y.float().abs().max()) == 0.0
+    torch.as_strided(y, (25,), (1,))[24] = 1.0                      # one element past the end
+    assert t.check() == [(0, 48, "above")]
+    z = t.alloc((4,), torch.int32, "cuda", poison=True, fallback=None)
+    torch.as_strided(z, (1,), (1,), storage_offset=z.storage_offset() - 1).fill_(7)   # one element below the start
+    assert t.check() == [(0, 16, "below")]
+    if os.environ.get("FK_TEST_POISON") == "1":
+        assert isinstance(K.torch, poison._Proxy)
+        n0 = K.torch._t.count
+        K.gelu_fwd(torch.zeros(64, device="cuda"))
+        assert K.torch._t.count == n0 + 1
+
+
 def test_shadow_refresh_single_launch(K):
     """fk_cast_pack_multi (engine.refresh_shadows): every weight shadow re-packed in one launch == the per-weight packs."""
     import frankenstein_amd as fa
