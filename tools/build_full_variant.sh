@@ -6,8 +6,8 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p $ROOT/frankenstein_amd/variants /tmp/fkvar/$NAME
 OBJS=""
-for s in gemm attention norm elementwise loss_optim pipeline conv decode; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form \
+for s in gemm attention norm elementwise loss_optim pipeline conv decode head_ce; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form \
     -I$ROOT/frankenstein_amd/csrc -I$ROOT/include "$@" -c $ROOT/frankenstein_amd/csrc/$s.hip -o /tmp/fkvar/$NAME/$s.o 2>/dev/null &
   OBJS="$OBJS /tmp/fkvar/$NAME/$s.o"
 done
