@@ -300,21 +300,29 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const T* dy, const 
   for (int i = threadIdx.x; i < 2 * dim; i += blockDim.x)
     part[(int64_t)blockIdx.x * 2 * dim + i] = red[i] + red[2 * dim + i] + red[4 * dim + i] + red[6 * dim + i];
 }
-// out[which][c] = sum_k part[k][which][c]; block = 64 columns x 16 slices (short dependent chains)
+// out[which][c] = sum_k part[k][which][c]; block = 16 columns x 64 slices: 48 blocks at dim = 384 and 16 loads per thread for 1024 partial
+// rows (the 64-column x 16-slice form before it ran 12 blocks with 64 dependent loads per thread: 16 us for 3 MB).  Fixed summation
+// tree: slice sums, then 4 x 16, then 4 -> deterministic.
 __global__ __launch_bounds__(1024) void norm_bwd_fused_final(const float* part, float* dgamma, float* dbeta, int dim, int nblk, int accumulate) {
-  __shared__ float sh[16][64];
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, which = blockIdx.y;
+  __shared__ float sh[64][17];
+  __shared__ float sh2[4][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl, which = blockIdx.y;
   float s = 0.0f;
   if (c < dim)
-    for (int k = sl; k < nblk; k += 16) s += part[((int64_t)k * 2 + which) * dim + c];
+    for (int k = sl; k < nblk; k += 64) s += part[((int64_t)k * 2 + which) * dim + c];
   sh[sl][cl] = s;
   __syncthreads();
-  if (sl == 0 && c < dim) {
+  if (threadIdx.x < 64) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[sl * 16 + i][cl];
+    sh2[sl][cl] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && c < dim) {
     float* out = which == 0 ? dgamma : dbeta;
     if (out) {
-      float t = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t += sh[i][cl];
+      const float t = (sh2[0][cl] + sh2[1][cl]) + (sh2[2][cl] + sh2[3][cl]);
       out[c] = accumulate ? out[c] + t : t;
     }
   }
@@ -443,7 +451,7 @@ int fk_norm_bwd(const void* dy, const void* x, const float* gamma, const float* 
 #undef FK_NB
     FK_CHECK_LAUNCH("fk_norm_bwd(fused)");
     if (want) {
-      hipLaunchKernelGGL(norm_bwd_fused_final, dim3((unsigned)fk_cdiv(dim, 64), 2), dim3(1024), 0, s, (const float*)part, dgamma, dbeta, (int)dim, (int)nbf, accumulate);
+      hipLaunchKernelGGL(norm_bwd_fused_final, dim3((unsigned)fk_cdiv(dim, 16), 2), dim3(1024), 0, s, (const float*)part, dgamma, dbeta, (int)dim, (int)nbf, accumulate);
       FK_CHECK_LAUNCH("fk_norm_bwd(fused final)");
     }
     return FK_OK;
