@@ -1310,6 +1310,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(TnArgs p) {
   }
 }
 
+// the same sum in the same order (slab 0, 1, 2, ...) on 16-byte vectors with eight slab loads in flight per thread
+__global__ __launch_bounds__(256) void reduce_slabs4_kernel(const float* ws, float* C, int64_t ldc, int N1, int N2, int nsplit, int accumulate) {
+  const int64_t total = (int64_t)N1 * N2, total4 = total >> 2;
+  const int n2v = N2 >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(ws) + i;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + u) * total4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; ++k) s += src[(int64_t)k * total4];
+    f32x4* dst = reinterpret_cast<f32x4*>(C + (i / n2v) * ldc + (i % n2v) * 4);
+    if (accumulate) s += *dst;
+    *dst = s;
+  }
+}
 __global__ void reduce_slabs_kernel(const float* ws, float* C, int64_t ldc, int N1, int N2, int nsplit, int accumulate) {
   const int64_t total = (int64_t)N1 * N2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1570,9 +1591,15 @@ int fk_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
   FK_CHECK_LAUNCH("fk_gemm_tn");
   if (ns > 1) {
     const int64_t total = N1 * N2;
-    int nb = (int)fk_cdiv(total, 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nb), dim3(256), 0, s, (const float*)workspace, C, ldc, (int)N1, (int)N2, ns, accumulate);
+    if (N2 % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)C | (uintptr_t)workspace) & 15) == 0) {
+      int nb = (int)fk_cdiv(total / 4, 256);
+      if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(reduce_slabs4_kernel, dim3(nb), dim3(256), 0, s, (const float*)workspace, C, ldc, (int)N1, (int)N2, ns, accumulate);
+    } else {
+      int nb = (int)fk_cdiv(total, 256);
+      if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nb), dim3(256), 0, s, (const float*)workspace, C, ldc, (int)N1, (int)N2, ns, accumulate);
+    }
     FK_CHECK_LAUNCH("fk_gemm_tn(reduce)");
   }
   return FK_OK;
