@@ -1,5 +1,6 @@
 """Opt-in memory checks for the GPU suite (FK_TEST_POISON=1): every buffer the product allocates through torch.empty / empty_like / zeros in
-frankenstein_amd.kernels and frankenstein_amd.engine (outputs, workspaces, saved activations) is carved out of a larger allocation with a
+frankenstein_amd.kernels, .engine, .models.brainformer, .models.gpt2_model and .utils.data_utils (outputs, workspaces, saved activations,
+key/value caches) is carved out of a larger allocation with a
 4-KiB guard band on both sides, and `empty` buffers are filled with 0xFF bytes (NaN in fp32 / bf16, -1 in integers) instead of whatever the
 caching allocator hands back.  After each test the bands are compared with their pattern: a kernel that writes past either end of its
 output fails the test that ran it, and a kernel that leaves part of an output unwritten shows up as NaN in whatever consumes it —
@@ -76,8 +77,10 @@ class Tracker:
 
 def install():
     from frankenstein_amd import engine, kernels
+    from frankenstein_amd.models import brainformer, gpt2_model
+    from frankenstein_amd.utils import data_utils
     tracker = Tracker()
     proxy = _Proxy(tracker)
-    kernels.torch = proxy
-    engine.torch = proxy
+    for mod in (kernels, engine, brainformer, gpt2_model, data_utils):
+        mod.torch = proxy
     return tracker
