@@ -479,6 +479,97 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(NtArgs p) {
   }
 }
 
+template <int N> FK_DEV void vm_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// Short-latency form of gemm_nt_glds_kernel for grids of at most one tile per CU (the perceiver's and the decoder's projections: 1024 rows,
+// 24 tiles).  There the launch is one tile's dependent chain, and with two k-stages in the ring every stage paid a full request latency
+// behind a vmcnt(0): 6 stages x ~1.5 us for K = 384.  Here the ring has four 32-KiB slots, three stages are requested before the first
+// product, and the waits are counted (vmcnt retires in order; 8 requests per wave and stage), one barrier per stage:
+//   wait for stage kt (own pieces) -> barrier (everyone's pieces; everyone has left stage kt - 1) -> request stage kt + 3 into the
+//   slot of stage kt - 1 -> multiply stage kt.
+// The epilogue stages through slot 3 behind one more barrier; the next tile's first stages follow it (see gemm_nt_glds_kernel).
+constexpr int G4_LDS = 4 * 2 * TILE_BYTES;
+static_assert(G4_LDS <= 160 * 1024, "LDS of a CU");
+template <typename TO>
+__global__ __launch_bounds__(NTHREADS, 1) void gemm_nt_glds4_kernel(NtArgs p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntiles = ((p.M + BM - 1) / BM) * ntn;
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = (nb + 7 - xcd) >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int t_beg = xcd * q8 + min(xcd, r8), t_end = t_beg + q8 + (xcd < r8 ? 1 : 0);
+
+  const T* srcA[4];
+  const T* srcB[4];
+  auto set_src = [&](int tile) {
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (wave * 4 + j) * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      srcA[j] = (const T*)p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
+      srcB[j] = (const T*)p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + ch * 8;
+    }
+  };
+  auto stage = [&](int buf, int k0) __attribute__((always_inline)) {
+    char* as = smem + buf * 2 * TILE_BYTES + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[j] + k0), (lds_void_t*)(as + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[j] + k0), (lds_void_t*)(as + TILE_BYTES + j * 1024), 16, 0, 0);
+    }
+  };
+  const int nk = p.K / 64;
+  auto head = [&]() __attribute__((always_inline)) {
+    stage(0, 0);
+    if (nk > 1) stage(1, 64);
+    if (nk > 2) stage(2, 128);
+  };
+  int tile = t_beg + jb;
+  if (tile < t_end) { set_src(tile); head(); }
+  for (; tile < t_end; tile += nbx) {
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int after = nk - 1 - kt;                 // stages requested behind stage kt at this point: min(after, 2)
+      if (after >= 2) vm_wait_barrier<16>(); else if (after == 1) vm_wait_barrier<8>(); else vm_wait_barrier<0>();
+      if (kt + 3 < nk) stage((kt + 3) & 3, (kt + 3) * 64);
+      const char* as = smem + (kt & 3) * 2 * TILE_BYTES;
+      const char* bs = as + TILE_BYTES;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) nt_frag<T>(fa[i], as, wm * 64 + i * 32 + li, s, lh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) nt_frag<T>(fb[j], bs, wn * 64 + j * 32 + li, s, lh);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fb[j], fa[i]);
+      }
+    }
+    __syncthreads();                                 // every wave has read the last stage (it may sit in slot 3, the staging area)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x16 (&sub)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i][0]);
+      nt_epilogue<T, TO, false, 1>(p, sub, smem + 3 * 2 * TILE_BYTES + wave * 8192, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, false);
+    }
+    if (tile + nbx < t_end) { set_src(tile + nbx); head(); }
+  }
+}
+
 // Large-tile variant for the big projections: 256 x BN_ block tile (BN_ = 256 or 128), 8 waves (2 per SIMD), wave tile
 // (256/WROWS) x 64.  A 128x128 tile needs 64 B of L2->LDS traffic per MFMA cycle per CU at full rate, more than the L2
 // fabric delivers (measured ~8 TB/s chip-wide on the small-tile kernel); 256x256 halves that (32 B/cycle) and gives each
@@ -577,9 +668,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(NtArgs p) {
 //   N = 384-class : gemm_nt_ring_kernel<128, 128, 3>: 256 x 128 tile, 64-element k-stages (128-B image rows), 2 x 48 KiB in flight
 //   N >= 1024     : gemm_nt_ring2_kernel below: 256 x 256 tile with separate A / B rings
 // (a 256 x 256 tile with 32-element stages, <256, 64, 4>, also works but its 64-byte requests fetch 1.4x slower per byte).
-template <int N> FK_DEV void vm_wait_barrier() {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 template <int BN_, int RB, int NS> struct Ring {
   static constexpr int BM_ = 256;
   static constexpr int STAGE = (BM_ + BN_) * RB, A_BYTES = BM_ * RB;
@@ -1508,6 +1596,18 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
       hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 256>), bgrid, bblock, bsh, s, p); }
     else { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<float, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess); (void)once;
       hipLaunchKernelGGL((gemm_nt_big_kernel<float, 256>), bgrid, bblock, bsh, s, p); }
+    FK_CHECK_LAUNCH(name);
+    return FK_OK;
+  }
+  static const bool no_g4 = getenv("FK_NT_NO_GLDS4") != nullptr;       // tuning knob
+  if (glds && nwg <= 256 && !no_g4) {                      // at most one tile per CU: the short-latency ring
+    if (out_dtype == FK_BF16) {
+      static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds4_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS) == hipSuccess); (void)once;
+      hipLaunchKernelGGL((gemm_nt_glds4_kernel<bf16_t>), grid, block, G4_LDS, s, p);
+    } else {
+      static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds4_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS) == hipSuccess); (void)once;
+      hipLaunchKernelGGL((gemm_nt_glds4_kernel<float>), grid, block, G4_LDS, s, p);
+    }
     FK_CHECK_LAUNCH(name);
     return FK_OK;
   }
