@@ -1567,7 +1567,11 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
   hipStream_t s = (hipStream_t)stream;
   const bool glds = dtype == FK_BF16 && (K % 64 == 0);
   static const bool no_ring = getenv("FK_NT_NO_RING") != nullptr;       // tuning knob: the double-buffered kernels instead
-  static const int ring_min = getenv("FK_NT_RING_MIN_TILES") ? atoi(getenv("FK_NT_RING_MIN_TILES")) : 0;
+  // the persistent ring kernels want several 256-row tiles per CU; below half a tile per CU (SimpleMAE's 4800 visible-token rows at
+  // B = 32) the 128 x 128 kernels fill the chip better: graphed cfg5 step 5.9 -> 5.6 ms (profiles/r03_g_other_configs.txt)
+  // (read per call, not cached: the GPU suite switches it to send small shapes through the ring kernels)
+  const char* ring_min_env = getenv("FK_NT_RING_MIN_TILES");
+  const int ring_min = ring_min_env ? atoi(ring_min_env) : 128;
   const bool wide = glds && M >= 4096 && vec_epi && !no_ring && fk_cdiv(M, 256) * fk_cdiv(N, 256) >= ring_min;
   if (wide && (N % 256 == 0 || (N % 128 == 0 && N >= 1024))) {   // 256 x 256 tiles, split A/B rings (N = 1152: the last column tile is
                                                                   // half empty, still 4 % faster than 256 x 128 tiles)

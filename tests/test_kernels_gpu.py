@@ -138,12 +138,18 @@ RING_SHAPES = [(4096, 384, 64), (4168, 128, 128), (8200, 1152, 384), (4104, 256,
                (4224, 384, 1536), (8200, 128, 1024), (70000, 384, 1088), (4096, 640, 3072)]
 
 
+@pytest.mark.parametrize("routing", ["ring", "default"])
 @pytest.mark.parametrize("shape", RING_SHAPES)
-def test_gemm_nt_ring_kernels_exact_integers(K, shape):
+def test_gemm_nt_ring_kernels_exact_integers(K, shape, routing, monkeypatch):
     """the ring-buffered wide-projection kernels (bf16, M >= 4096, N % 128 == 0, K % 64 == 0): one and several tiles per persistent
     block (the stage stream crosses tile boundaries), a single k-stage, fewer stages than ring slots, ragged last row tile, 256- and
     128-column tiles.  Integer operands make every sum exact: fp32 output must be bit-equal to the reference, bf16 output to its
-    single rounding; bias / residual / periodic residual ride on the same epilogue."""
+    single rounding; bias / residual / periodic residual ride on the same epilogue.  routing "ring": every shape goes to the ring
+    kernels (FK_NT_RING_MIN_TILES=0; by default grids under 128 tiles of 256 rows take the 128 x 128 kernels, routing "default")."""
+    if routing == "ring":
+        monkeypatch.setenv("FK_NT_RING_MIN_TILES", "0")
+    else:
+        monkeypatch.delenv("FK_NT_RING_MIN_TILES", raising=False)
     M, N, Kd = shape
     g = torch.Generator().manual_seed(7)
     a = torch.randint(-2, 3, (M, Kd + 8), generator=g).float()
@@ -164,9 +170,10 @@ def test_gemm_nt_ring_kernels_exact_integers(K, shape):
     assert torch.equal(got.float().cpu(), (ref + tab[torch.arange(M) % 24]).to(torch.bfloat16).float())
 
 
-def test_gemm_nt_ring_fused_epilogues_match_small_kernel(K):
+def test_gemm_nt_ring_fused_epilogues_match_small_kernel(K, monkeypatch):
     """SwiGLU-forward and RoPE epilogues on the ring kernels (M >= 4096) against the same rows computed in < 4096-row pieces,
     which take the 128x128 kernel: bit-identical (same accumulation order over k, same epilogue code)."""
+    monkeypatch.setenv("FK_NT_RING_MIN_TILES", "0")            # these grids are under the default threshold of the ring kernels
     M, d, H = 4096 + 520, 128, 256
     x, w13 = dev(rnd(M, d, seed=1), torch.bfloat16), dev(rnd(2 * H, d, seed=2, scale=0.2), torch.bfloat16)
     h13, gq = K.gemm_nt_swiglu(x, w13)
