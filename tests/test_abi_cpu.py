@@ -38,6 +38,15 @@ def test_library_loads_and_exports_every_symbol(built):
     assert lib.fk_last_error() is not None
 
 
+def test_graft_entry_build_runs(built):
+    """the driver's build check (`__graft_entry__.build()`): builds, loads, and finds the version the header declares"""
+    import __graft_entry__ as g
+    g.build()
+    from frankenstein_amd import _lib
+    txt = (ROOT / "include" / "franken_hip.h").read_text()
+    assert _lib.lib().fk_version() == int(re.search(r"#define FK_VERSION (\d+)", txt).group(1)) == 301
+
+
 def test_argument_validation_needs_no_gpu(built):
     """Bad arguments are rejected on the host before any launch (error convention of SURVEY §8b)."""
     from frankenstein_amd import _lib
