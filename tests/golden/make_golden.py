@@ -450,8 +450,33 @@ def accum_golden():
          **{"param/" + k: v.detach().numpy() for k, v in params_of(m).items()})
 
 
+def cfg2_batch_golden(B=3):
+    """cfg2 (brainformer-small, N = 6144 tokens, L1 head) at B = 3: the full-size shape with more than one sample and a batch that is
+    not a power of two — loss, predictions, encoder rows of every sample, gradient summaries and evenly spaced gradient samples."""
+    bf, g2, tu = import_reference()
+    from tests import cases as TC
+    enc = bf.MAEConfig(window_size=600, n_electrodes=256, patch_size=25, dim=384, n_layers=6, head_dim=64,
+                       hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=384, n_layers=2, head_dim=64,
+                    hidden_dim=768, n_heads=6, n_kv_heads=6)
+    m = bf.BrainFormer(cfg).float()
+    load_synth(m)
+    x = torch.from_numpy(synth.make_inputs(B, 600, 256))
+    tgt = torch.from_numpy(synth.make_motion_targets(B, 32, 128))
+    loss, pred = m(x, tgt)
+    loss.backward()
+    with torch.no_grad():
+        ctx = m.encoder(x)
+    gn, gr = summarize(grads_of(m))
+    sn, sr = TC.sample_rows(grads_of(m))
+    save(f"cfg2_b{B}", loss=np.array(float(loss)), pred=pred.detach().numpy(), enc_rows=ctx[:, [0, 1, 255, 256, 3071, 6143]].numpy(),
+         grad_names=gn, grad_rows=gr, grad_samples=sr)
+
+
 if __name__ == "__main__":
-    if os.environ.get("FK_GOLDEN_ONLY") == "pipeline":
+    if os.environ.get("FK_GOLDEN_ONLY") == "cfg2_b3":
+        cfg2_batch_golden()
+    elif os.environ.get("FK_GOLDEN_ONLY") == "pipeline":
         pipeline_golden()
     elif os.environ.get("FK_GOLDEN_ONLY") == "vq_conv_small":
         vq_golden()
@@ -462,3 +487,4 @@ if __name__ == "__main__":
         pipeline_golden()
         vq_golden()
         accum_golden()
+        cfg2_batch_golden()

@@ -362,6 +362,38 @@ def test_cfg2_b1_fp32(golden):
     check_grad_rows(m, z, rtol=5e-3, atol=5e-4)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_cfg2_b3_vs_reference(golden, mode):
+    """The benchmarked shape with MORE THAN ONE sample (B = 3: batch strides at N = 6144, a batch that is not a power of two) against the
+    reference's fp32 CPU run (tests/golden/cfg2_b3.npz): fp32 mode to the B = 1 test's bounds, bf16 mode to the bounds of
+    test_cfg2_b1_bf16_vs_reference."""
+    from frankenstein_amd.models import brainformer as bf
+    z = golden("cfg2_b3")
+    fa.set_compute_dtype(mode)
+    try:
+        cfgo, x, tgt = C.cfg2(3)
+        m = mk_bf(cfgo, bf.BrainFormer)
+        loss, pred = m(x.cuda(), tgt.cuda())
+        with torch.no_grad():
+            ctx = m.encoder(x.cuda())
+        loss.backward()
+        rows = ctx[:, [0, 1, 255, 256, 3071, 6143]].float().cpu().numpy()
+        perr = float((pred.float().cpu().detach() - torch.from_numpy(z["pred"])).abs().max())
+        eerr = float(np.abs(rows - z["enc_rows"]).max())
+        if mode == "fp32":
+            assert abs(float(loss) - float(z["loss"])) < 1e-4
+            assert perr < 1e-3 and eerr < 1e-3, (perr, eerr)
+            check_grad_rows(m, z, rtol=5e-3, atol=5e-4)
+        else:
+            rel = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+            cos = _cosines(m, z)
+            worst = min(cos, key=cos.get)
+            assert rel < 1e-2 and perr < 5e-2 and eerr < 0.03 * max(1.0, float(np.abs(z["enc_rows"]).max())), (rel, perr, eerr)
+            assert cos[worst] >= 0.99, (worst, cos[worst])
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
 def _cosines(model, z):
     """per-parameter cosine between this model's gradients and the reference's, on the fixture's evenly spaced samples"""
     names, rows = C.sample_rows(named_grads(model))

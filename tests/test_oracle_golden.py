@@ -150,6 +150,21 @@ def test_cfg2_b1(golden):
         np.testing.assert_allclose(r, want[n], rtol=2e-3, atol=2e-4, err_msg=n)
 
 
+def test_cfg2_b3(golden):
+    """the full-size shape with three samples: the oracle reproduces the reference's loss, predictions and gradient summaries"""
+    z = golden("cfg2_b3")
+    cfg, x, tgt = C.cfg2(3)
+    sd = leafify(C.state(R.brainformer_shapes(cfg, "to_motion")))
+    loss, pred = R.brainformer_l1(sd, x, tgt, cfg)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    np.testing.assert_allclose(pred.detach().numpy(), z["pred"], atol=1e-4)
+    g = grads(loss, sd)
+    names, rows = C.summarize_rows(g)
+    want = {str(n): r for n, r in zip(z["grad_names"], z["grad_rows"])}
+    for n, r in zip(names, rows):
+        np.testing.assert_allclose(r, want[n], rtol=2e-3, atol=2e-4, err_msg=n)
+
+
 def test_cfg2_b1_gradient_samples_and_ce_head(golden):
     """The two fixtures added for the benchmarked shape: evenly spaced samples of every gradient of the L1-head run, and the
     CE-head variant (notebook class, 25 output tokens, V = 50257) — the oracle reproduces both."""
