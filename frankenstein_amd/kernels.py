@@ -195,7 +195,9 @@ class Mask:
         (models/brainformer.py:160-168).  Stored as uint8 [Bm, t_q, t_k] for the per-element path of the generic kernels."""
         m = mask[..., mask.shape[-2] - t_q:, mask.shape[-1] - t_k:]
         lead = [d for d in m.shape[:-2] if d != 1]
-        assert len(lead) <= 1, f"dense attention mask with more than one batch-like dimension: {tuple(mask.shape)}"
+        if len(lead) > 1:
+            raise NotImplementedError(f"dense attention mask {tuple(mask.shape)}: one mask per sample is supported (heads share it), "
+                                      "not one per (sample, head)")
         bm = lead[0] if lead else 1
         u8 = m.reshape(bm, t_q, t_k).to(torch.uint8).contiguous()
         return Mask(MASK_DENSE, 0 if bm == 1 else t_q * t_k, 0, 0, u8, None)

@@ -710,6 +710,8 @@ def test_attention_dense_mask_agrees_with_the_analytic_kinds(K):
     K.attn_bwd(qv, kv, vv, o, do, lse, dq, dk, dv, m)
     assert float(o[:, 5].abs().max()) == 0.0 and float(dq[:, 5].abs().max()) == 0.0
     assert all(bool(torch.isfinite(t_).all()) for t_ in (o, dq, dk, dv))
+    with pytest.raises(NotImplementedError, match="per"):
+        K.Mask.from_dense(torch.ones(2, 3, N, N, dtype=torch.bool, device="cuda"), N, N)
     from frankenstein_amd._lib import FrankenHipError
     with pytest.raises(FrankenHipError, match="dense mask"):
         K.attn_fwd(qv.bfloat16().repeat(1, 1, 1, 2), kv.bfloat16().repeat(1, 1, 1, 2), vv.bfloat16().repeat(1, 1, 1, 2), m, q_prescaled=True)
