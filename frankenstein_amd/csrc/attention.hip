@@ -67,9 +67,10 @@ FK_DEV bool visible(int kind, int c, int qpos, int kpos) {
 }
 // exclusive upper bound of key INDICES visible to query index q (monotone predicates only)
 // FK_MASK_DENSE: an arbitrary boolean mask (models/brainformer.py:160-168 passes whatever it is given): `limits` points to uint8
-// [Bm, Nq, Nk] (non-zero = attend), mask_c is the batch stride in elements (0: one mask for every sample); heads share it
-FK_DEV bool dense_vis(const AttnArgs& p, int b, int q, int k) {
-  return reinterpret_cast<const unsigned char*>(p.limits)[(int64_t)b * p.mask_c + (int64_t)q * p.Nk + k] != 0;
+// [Bm, Hm, Nq, Nk] (non-zero = attend), mask_c is the batch stride and q_off the head stride in elements (0: one mask for every sample /
+// every head; the position offsets q_off / k_off have no meaning for a table)
+FK_DEV bool dense_vis(const AttnArgs& p, int b, int hd, int q, int k) {
+  return reinterpret_cast<const unsigned char*>(p.limits)[(int64_t)b * p.mask_c + (int64_t)hd * p.q_off + (int64_t)q * p.Nk + k] != 0;
 }
 FK_DEV int kv_limit(const AttnArgs& p, int b, int q) {
   if (p.mask_kind == FK_MASK_PREFIX) return min(p.Nk, p.limits[(int64_t)b * p.Nq + q]);
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kb + 32 * u + acc_row(r, lh);
-          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : (dense ? (q_ok && dense_vis(p, b, qrow, key)) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))))) sc[u][r] = -INFINITY;
+          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : (dense ? (q_ok && dense_vis(p, b, hd, qrow, key)) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))))) sc[u][r] = -INFINITY;
         }
     }
     float tmax = -INFINITY;
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) {
           float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
           const int key = kb + 32 * u + acc_row(r, lh);
-          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : (dense ? (q_ok && dense_vis(p, b, qrow, key)) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))))) pv = 0.0f;
+          if (!(key < p.Nk && (prefix ? key < my_lim : (keypad ? (my_lim != 0 && p.qfirst[(int64_t)b * p.Nk + key] != 0) : (dense ? (q_ok && dense_vis(p, b, hd, qrow, key)) : visible(p.mask_kind, p.mask_c, qpos, key + p.k_off)))))) pv = 0.0f;
           float dpv = dp[r];
           if (p.drop_thresh) dpv = drop_keep(dkey, drow, (unsigned)key) ? dpv * p.drop_scale : 0.0f;     // d(P) through the dropout
           sc[r] = pv * (dpv - dl);   // dS^T (without the softmax scale; folded into the final store)
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && D <= 64) ? 2 : 1) void attn_
             const int r = 4 * g + j;
             float pv = __builtin_amdgcn_exp2f(sc[u][r] * c + l4[j]);
             const int q = qb + 32 * u + acc_row(r, lh);
-            if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : (dense ? (q < p.Nq && dense_vis(p, b, q, krow)) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos)))))) pv = 0.0f;
+            if (!(k_ok && (prefix ? q >= my_qf : (keypad ? (my_qf != 0 && q < p.Nq && p.limits[(int64_t)b * p.Nq + q] != 0) : (dense ? (q < p.Nq && dense_vis(p, b, hd, q, krow)) : visible(p.mask_kind, p.mask_c, q + p.q_off, kpos)))))) pv = 0.0f;
             float dpv = dp[u][r];
             if (p.drop_thresh) {     // dV takes the dropped, rescaled P; dP comes back through the same mask
               const bool keep = drop_keep(dkey, drop_row(dkey, (unsigned)((b * p.H + hd) * p.Nq + q)), (unsigned)krow);
@@ -2347,7 +2348,8 @@ int fk_attn_fwd_dropout(const void* Q, const void* K, const void* V, void* O, fl
   a.B = (int)B; a.H = (int)H; a.Nq = (int)Nq; a.Nk = (int)Nk;
   a.mask_kind = mask_kind; a.mask_c = (int)mask_c; a.q_off = (int)q_off; a.k_off = (int)k_off; a.scale = scale;
   FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_fwd: prefix / key-padding masks need both tables");
-  FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (limits && !(flags & FK_ATTN_Q_PRESCALED)), "fk_attn_fwd: a dense mask needs its uint8 table in `limits` and the generic kernels (no FK_ATTN_Q_PRESCALED)");
+  FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (limits && !(flags & FK_ATTN_Q_PRESCALED) && q_off >= 0 && q_off < (1LL << 31) && k_off == 0),
+               "fk_attn_fwd: a dense mask needs its uint8 table in `limits`, its head stride (>= 0) in q_off, k_off = 0 and the generic kernels (no FK_ATTN_Q_PRESCALED)");
   a.limits = limits; a.qfirst = qfirst; a.flags = flags;
   rc = set_dropout("fk_attn_fwd", a, drop_p, drop_seed, drop_site, flags);
   if (rc) return rc;
@@ -2387,7 +2389,8 @@ int fk_attn_bwd_dropout(const void* Q, const void* K, const void* V, const void*
   FK_CHECK_ARG(!rope_table || (Nq == Nk && D % 4 == 0 && ((uintptr_t)rope_table & 15) == 0), "fk_attn_bwd: fused inverse RoPE needs self-attention (Nq == Nk)");
   a.rope_table = rope_table; a.rope_bs = rope_bs; a.rope_off = (int)rope_off;
   FK_CHECK_ARG((mask_kind != FK_MASK_PREFIX && mask_kind != FK_MASK_KEYPAD) || (limits && qfirst), "fk_attn_bwd: prefix / key-padding masks need both tables");
-  FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (limits && !(flags & FK_ATTN_Q_PRESCALED)), "fk_attn_bwd: a dense mask needs its uint8 table in `limits` and the generic kernels (no FK_ATTN_Q_PRESCALED)");
+  FK_CHECK_ARG(mask_kind != FK_MASK_DENSE || (limits && !(flags & FK_ATTN_Q_PRESCALED) && q_off >= 0 && q_off < (1LL << 31) && k_off == 0),
+               "fk_attn_bwd: a dense mask needs its uint8 table in `limits`, its head stride (>= 0) in q_off, k_off = 0 and the generic kernels (no FK_ATTN_Q_PRESCALED)");
   a.limits = limits; a.qfirst = qfirst; a.flags = flags;
   rc = set_dropout("fk_attn_bwd", a, drop_p, drop_seed, drop_site, flags);
   if (rc) return rc;

@@ -190,17 +190,19 @@ class Mask:
 
     @staticmethod
     def from_dense(mask: Tensor, t_q: int, t_k: int) -> "Mask":
-        """Any boolean mask (True = attend) of shape [.., N_q, N_k] with at most one non-unit leading dimension (the batch; heads share the
-        mask): the reference's attention takes whatever tensor it is given and slices it as mask[..., -t_q:, -t_k:]
-        (models/brainformer.py:160-168).  Stored as uint8 [Bm, t_q, t_k] for the per-element path of the generic kernels."""
+        """Any boolean mask (True = attend) broadcastable to [B, H, N_q, N_k] — [N, N], [B, 1, N, N], [1, H, N, N], [B, H, N, N]: the
+        reference's attention takes whatever tensor it is given and slices it as mask[..., -t_q:, -t_k:] (models/brainformer.py:160-168).
+        Stored as uint8 [Bm, Hm, t_q, t_k] for the per-element path of the generic kernels (c = batch stride, q_off = head stride)."""
         m = mask[..., mask.shape[-2] - t_q:, mask.shape[-1] - t_k:]
-        lead = [d for d in m.shape[:-2] if d != 1]
-        if len(lead) > 1:
-            raise NotImplementedError(f"dense attention mask {tuple(mask.shape)}: one mask per sample is supported (heads share it), "
-                                      "not one per (sample, head)")
-        bm = lead[0] if lead else 1
-        u8 = m.reshape(bm, t_q, t_k).to(torch.uint8).contiguous()
-        return Mask(MASK_DENSE, 0 if bm == 1 else t_q * t_k, 0, 0, u8, None)
+        if m.dim() > 4:
+            if any(d != 1 for d in m.shape[:-4]):
+                raise NotImplementedError(f"dense attention mask {tuple(mask.shape)}: at most [B, H, N_q, N_k]")
+            m = m.reshape(m.shape[-4:])
+        while m.dim() < 4:
+            m = m.unsqueeze(0)
+        bm, hm = m.shape[0], m.shape[1]
+        u8 = m.to(torch.uint8).contiguous()
+        return Mask(MASK_DENSE, 0 if bm == 1 else hm * t_q * t_k, 0 if hm == 1 else t_q * t_k, 0, u8, None)
 
     @staticmethod
     def from_padding(q_valid: Tensor, k_valid: Tensor) -> "Mask":

@@ -87,8 +87,9 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
  * visible(q,k) = k < limits[b,q] <=> q >= qfirst[b,k], int32 tables from fk_prefix_mask.
  * KEYPAD (padding mask of models/simple_mae:228-236,349-352): visible(q,k) = limits[b,q] != 0 && qfirst[b,k] != 0, i.e. the two
  * int32 tables are the query / key validity flags.  DENSE (any boolean mask: models/brainformer.py:160-168 passes whatever it is given):
- * `limits` points to uint8 [Bm, Nq, Nk] (non-zero = attend; heads share it), mask_c = its batch stride in elements (0: one mask for every
- * sample), qfirst unused; every tile takes the per-element path of the generic kernels (FK_ATTN_Q_PRESCALED is refused).
+ * `limits` points to uint8 [Bm, Hm, Nq, Nk] (non-zero = attend), mask_c = its batch stride and q_off its head stride in elements (0: one
+ * mask for every sample / every head), k_off = 0, qfirst unused; every tile takes the per-element path of the generic kernels
+ * (FK_ATTN_Q_PRESCALED is refused).
  * Fully masked rows give 0.  D in {8,16,32,64} (+128 for bf16).  Backward: dO shares O's strides, dQ/dK/dV share Q/K/V's strides; delta_ws
  * is fp32 scratch of 2 * B * H * roundup(Nq, 64) floats (the row statistics the dQ kernel hands to the dK/dV kernel).  rope_table != NULL
  * (self-attention only) additionally applies the inverse RoPE (rotation by -angle at position rope_off + index) to dQ and dK as they are

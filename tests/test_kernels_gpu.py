@@ -651,12 +651,14 @@ def test_attention_prefix_mask_from_token_ids(K, dtype):
 
 
 DENSE_CASES = [
-    # B, H, Nq, Nk, D, one mask per sample
-    (2, 2, 200, 200, 64, True),
-    (1, 3, 57, 300, 32, False),
-    (2, 2, 128, 256, 16, True),
-    (3, 2, 8, 8, 8, False),
-    (2, 1, 320, 192, 64, False),
+    # B, H, Nq, Nk, D, one mask per sample, one mask per head
+    (2, 2, 200, 200, 64, True, False),
+    (1, 3, 57, 300, 32, False, False),
+    (2, 2, 128, 256, 16, True, False),
+    (3, 2, 8, 8, 8, False, False),
+    (2, 1, 320, 192, 64, False, False),
+    (2, 3, 130, 200, 32, True, True),
+    (2, 2, 64, 96, 64, False, True),
 ]
 
 
@@ -665,14 +667,15 @@ DENSE_CASES = [
 def test_attention_dense_boolean_mask(K, dtype, case):
     """FK_MASK_DENSE: any boolean mask, as the reference's attention hands it to SDPA (models/brainformer.py:160-168); heads share it,
     the batch may or may not.  Rows whose first key tiles are wholly masked and keys no query sees are part of the case."""
-    B, H, Nq, Nk, D, per_sample = case
+    B, H, Nq, Nk, D, per_sample, per_head = case
     g = torch.Generator().manual_seed(Nq * 7 + Nk)
-    mt = torch.rand(B if per_sample else 1, 1, Nq, Nk, generator=g) < 0.35
+    mt = torch.rand(B if per_sample else 1, H if per_head else 1, Nq, Nk, generator=g) < 0.35
     mt[..., : min(96, Nk - 1)] &= (torch.arange(Nq) % 3 != 0)[:, None]      # every third query: nothing visible in the first key tiles
     mt[..., Nk // 2] = False                                                 # a key without any query
     mt[..., Nk - 1] = True                                                   # and no empty row (NaN in the reference)
     m = K.Mask.from_dense(mt.cuda(), Nq, Nk)
-    assert m.limits.dtype == torch.uint8 and m.c == (Nq * Nk if per_sample and B > 1 else 0)
+    hm = H if per_head and H > 1 else 1
+    assert m.limits.dtype == torch.uint8 and m.c == (hm * Nq * Nk if per_sample and B > 1 else 0) and m.q_off == (Nq * Nk if hm > 1 else 0)
     qv, kv, vv, do = rnd(B, Nq, H, D, seed=1), rnd(B, Nk, H, D, seed=2), rnd(B, Nk, H, D, seed=3), rnd(B, Nq, H, D, seed=4)
     qd, kd, vd = dev(qv, dtype), dev(kv, dtype), dev(vv, dtype)
     o, lse = K.attn_fwd(qd, kd, vd, m)
@@ -710,8 +713,8 @@ def test_attention_dense_mask_agrees_with_the_analytic_kinds(K):
     K.attn_bwd(qv, kv, vv, o, do, lse, dq, dk, dv, m)
     assert float(o[:, 5].abs().max()) == 0.0 and float(dq[:, 5].abs().max()) == 0.0
     assert all(bool(torch.isfinite(t_).all()) for t_ in (o, dq, dk, dv))
-    with pytest.raises(NotImplementedError, match="per"):
-        K.Mask.from_dense(torch.ones(2, 3, N, N, dtype=torch.bool, device="cuda"), N, N)
+    with pytest.raises(NotImplementedError, match="at most"):
+        K.Mask.from_dense(torch.ones(2, 2, 3, N, N, dtype=torch.bool, device="cuda"), N, N)
     from frankenstein_amd._lib import FrankenHipError
     with pytest.raises(FrankenHipError, match="dense mask"):
         K.attn_fwd(qv.bfloat16().repeat(1, 1, 1, 2), kv.bfloat16().repeat(1, 1, 1, 2), vv.bfloat16().repeat(1, 1, 1, 2), m, q_prescaled=True)
