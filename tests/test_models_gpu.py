@@ -184,6 +184,30 @@ def test_gpt_dropout_training_step_matches_the_oracle_with_the_same_draws(bias):
     assert abs(float(le) - float(r0)) < 1e-5 and int(words[1]) == step0 + 2
 
 
+def test_gpt_dropout_bf16_mode_uses_the_same_draws():
+    """bf16 throughput mode with dropout: the draws do not depend on the compute dtype (same seed words, sites and indices), so the bf16
+    step stays within bf16 drift of the fp32 oracle evaluated with the predicted masks, and far from the dropout-free loss."""
+    from frankenstein_amd import engine as E
+    p, seed = 0.3, 777
+    torch.manual_seed(seed)
+    fa.set_compute_dtype("bf16")
+    try:
+        cfgo, prefix, tk, idx = C.gpt_small(True)
+        g = load_synth(mk_gpt(cfgo, dropout=p)).train()
+        sd = C.state(R.gpt_shapes(cfgo))
+        B, T = idx.shape[0], idx.shape[1] + prefix.shape[1]
+        words = E.dropout_words(torch.device("cuda", torch.cuda.current_device()))
+        step0 = int(words[1])
+        loss, _ = g(idx.cuda(), prefix=prefix.cuda(), targets=tk.cuda())
+        loss.backward()
+        rl, _ = R.gpt_forward(sd, idx, prefix, tk, cfgo, masks=iter(_gpt_drop_masks(cfgo, seed, step0 + 1, B, T, p)))
+        r0, _ = R.gpt_forward(sd, idx, prefix, tk, cfgo)
+        assert abs(float(loss) - float(rl)) < 3e-2 < abs(float(rl) - float(r0)), (float(loss), float(rl), float(r0))
+        assert all(torch.isfinite(v).all() for v in named_grads(g).values())
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
 def test_gpt_dropout_in_a_captured_graph_draws_new_masks_per_replay():
     """The seed words are read from device memory: a hipGraph of forward + backward gives a different draw on every replay, and each
     replay equals the eager step with the same step word."""
