@@ -570,6 +570,259 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
     p.LSE[((int64_t)b * p.H + hd) * p.Nq + qrow] = lt > 0.0f ? m * p.scale + logf(lt) : INFINITY;
 }
 
+// ================================================================================================= few queries, long context
+// The perceiver's read-out (models/brainformer.py:204-215): 32 query tokens against 6144 keys per (batch, head).  The kernels above give
+// such a launch one workgroup per (b, h) with ONE wave that has rows: 192 waves for the chip, each walking 6144 keys behind a barrier per
+// tile (138 us where streaming K and V once takes 60).  Here the eight waves of the workgroup split the KEYS: wave w takes the 32-key
+// tiles w, w + 8, ... through its OWN double-buffered LDS-DMA pipeline (8 KiB per tile, no barrier in the loop, counted vmcnt waits),
+// keeps its own online-softmax state, and the eight partial results are merged once through LDS (the exact combination rule of
+// fk_attn_combine).  bf16, D = 64, Nq <= 32, no mask, no dropout; everything else stays on attn_fwd_kernel.
+constexpr int FEWQ_NW = 8, FEWQ_BK = 32, FEWQ_TILE = 2 * FEWQ_BK * 128, FEWQ_LDS = FEWQ_NW * 2 * FEWQ_TILE;
+static_assert(FEWQ_LDS <= 160 * 1024 && FEWQ_NW * (32 * 64 * 4 + 2 * 64 * 4) <= FEWQ_LDS, "LDS of a CU; the merge area fits the tile buffers");
+
+__global__ __launch_bounds__(FEWQ_NW * 64) void attn_fwd_fewq_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.x, b = bh / p.H, hd = bh % p.H;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const int qrow = li;
+  const bool q_ok = qrow < p.Nq;
+  Frag<T> qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (q_ok) frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+    else frag_zero<T>(qf[s]);
+  }
+  char* buf = smem + wave * 2 * FEWQ_TILE;
+  const int ntiles = (p.Nk + FEWQ_BK - 1) / FEWQ_BK;
+  const int cnt = wave < ntiles ? (ntiles - wave + FEWQ_NW - 1) / FEWQ_NW : 0;       // this wave's tiles: wave, wave + 8, ...
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the Q fragments; from here on vmcnt counts this wave's tile requests only
+  auto request = [&](int i) __attribute__((always_inline)) {
+    char* img = buf + (i & 1) * FEWQ_TILE;
+    const int row0 = (wave + FEWQ_NW * i) * FEWQ_BK;
+    dma_tile_bf16_d64<FEWQ_BK, 1>(Kp, p.k_rs, row0, p.Nk, img, 0, lane);
+    dma_tile_bf16_d64<FEWQ_BK, 1>(Vp, p.v_rs, row0, p.Nk, img + FEWQ_BK * 128, 0, lane);
+  };
+  if (cnt > 0) request(0);
+  const float c = p.scale * LOG2E;
+  float m = -INFINITY, l = 0.0f;
+  f32x16 o[2];
+  zero_acc(o);
+  for (int i = 0; i < cnt; ++i) {
+    if (i + 1 < cnt) {
+      request(i + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 requests of tile i have landed, those of tile i + 1 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const char* kt = buf + (i & 1) * FEWQ_TILE;
+    const char* vt = kt + FEWQ_BK * 128;
+    const int kb = (wave + FEWQ_NW * i) * FEWQ_BK;
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Frag<T> kf;
+      img_row<T, D>(kf, kt, li, s, lh);
+      mma32<T>(sc, kf, qf[s]);
+    }
+    if (kb + FEWQ_BK > p.Nk) {            // the ragged last tile (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kb + acc_row(r, lh) >= p.Nk) sc[r] = -INFINITY;
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (__builtin_amdgcn_ballot_w64(tmax > m) != 0) {
+      const float m_new = fmaxf(m, tmax);
+      const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m - m_new) * c);
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float mc = (m == -INFINITY) ? 0.0f : m * c;
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(sc[r] * c - mc);
+      sc[r] = pv;
+      rs += pv;
+    }
+    l += rs;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> pf;
+      frag_from_acc<T>(pf, sc, s);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag<T> vf;
+        img_tr<T, D>(vf, vt, 0, s, 32 * dt, lane);
+        mma32<T>(o[dt], vf, pf);
+      }
+    }
+  }
+  // merge: every wave leaves (m, l, O) in the (now idle) tile buffers, wave 0 combines them in wave order (a fixed order: deterministic)
+  __syncthreads();
+  float* area = reinterpret_cast<float*>(smem);
+  constexpr int PER = 32 * 64 + 2 * 64;                    // floats per wave: 32 accumulator registers x 64 lanes, m, l
+  {
+    float* mine = area + wave * PER;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[(dt * 16 + r) * 64 + lane] = o[dt][r];
+    mine[32 * 64 + lane] = m;
+    mine[32 * 64 + 64 + lane] = l;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  float M = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < FEWQ_NW; ++w) M = fmaxf(M, area[w * PER + 32 * 64 + lane]);
+  float L = 0.0f;
+  zero_acc(o);
+#pragma unroll 1
+  for (int w = 0; w < FEWQ_NW; ++w) {
+    const float* theirs = area + w * PER;
+    const float mw = theirs[32 * 64 + lane];
+    const float aw = (mw == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f((mw - M) * c);
+    L += aw * theirs[32 * 64 + 64 + lane];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] += aw * theirs[(dt * 16 + r) * 64 + lane];
+  }
+  const float lt = L + __shfl_xor(L, 32, 64);
+  const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+  T* Op = (T*)p.Out + (int64_t)b * p.o_bs + hd * D;
+  store_rows_T<T, D>(Op, p.o_rs, qrow, q_ok, o, inv, lh);
+  if (q_ok && lh == 0 && p.LSE) p.LSE[((int64_t)b * p.H + hd) * p.Nq + qrow] = lt > 0.0f ? M * p.scale + logf(lt) : INFINITY;
+}
+
+// the query gradient of the same shape: wave-private key tiles as above; S = K Q^T and dP = V dO^T per tile, dS = P (dP - delta),
+// dQ^T += K^T dS; the eight partial dQ are summed through LDS in wave order.  Publishes delta for the dK/dV kernel like attn_bwd_dq_kernel.
+__global__ __launch_bounds__(FEWQ_NW * 64) void attn_bwd_dq_fewq_kernel(AttnArgs p) {
+  using T = bf16_t;
+  constexpr int D = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.x, b = bh / p.H, hd = bh % p.H;
+  const T* Qp = (const T*)p.Q + (int64_t)b * p.q_bs + hd * D;
+  const T* Kp = (const T*)p.K + (int64_t)b * p.k_bs + hd * D;
+  const T* Vp = (const T*)p.V + (int64_t)b * p.v_bs + hd * D;
+  const T* Gp = (const T*)p.dO + (int64_t)b * p.o_bs + hd * D;
+  const T* Op = (const T*)p.O + (int64_t)b * p.o_bs + hd * D;
+  const int qrow = li;
+  const bool q_ok = qrow < p.Nq;
+  Frag<T> qf[4], gf[4];
+  float part = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (q_ok) {
+      frag_load_contig<T>(qf[s], Qp + (int64_t)qrow * p.q_rs + 16 * s + 8 * lh);
+      frag_load_contig<T>(gf[s], Gp + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
+      Frag<T> of;
+      frag_load_contig<T>(of, Op + (int64_t)qrow * p.o_rs + 16 * s + 8 * lh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += to_f32<T>(of.v[e]) * to_f32<T>(gf[s].v[e]);
+    } else {
+      frag_zero<T>(qf[s]);
+      frag_zero<T>(gf[s]);
+    }
+  }
+  const int64_t stat = ((int64_t)b * p.H + hd) * p.Nq + qrow;
+  const float lse2 = q_ok ? p.LSE[stat] * LOG2E : INFINITY;   // +inf -> P = 0 for padded rows
+  const float dl = part + __shfl_xor(part, 32, 64);           // delta = rowsum(dO * O)
+  if (wave == 0 && q_ok && lh == 0) p.delta[stat] = dl;
+  char* buf = smem + wave * 2 * FEWQ_TILE;
+  const int ntiles = (p.Nk + FEWQ_BK - 1) / FEWQ_BK;
+  const int cnt = wave < ntiles ? (ntiles - wave + FEWQ_NW - 1) / FEWQ_NW : 0;
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the row fragments and statistics; from here on vmcnt counts this wave's tile requests only
+  auto request = [&](int i) __attribute__((always_inline)) {
+    char* img = buf + (i & 1) * FEWQ_TILE;
+    const int row0 = (wave + FEWQ_NW * i) * FEWQ_BK;
+    dma_tile_bf16_d64<FEWQ_BK, 1>(Kp, p.k_rs, row0, p.Nk, img, 0, lane);
+    dma_tile_bf16_d64<FEWQ_BK, 1>(Vp, p.v_rs, row0, p.Nk, img + FEWQ_BK * 128, 0, lane);
+  };
+  if (cnt > 0) request(0);
+  const float c = p.scale * LOG2E;
+  f32x16 dq[2];
+  zero_acc(dq);
+  for (int i = 0; i < cnt; ++i) {
+    if (i + 1 < cnt) {
+      request(i + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const char* kt = buf + (i & 1) * FEWQ_TILE;
+    const char* vt = kt + FEWQ_BK * 128;
+    const int kb = (wave + FEWQ_NW * i) * FEWQ_BK;
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Frag<T> kf, vf;
+      img_row<T, D>(kf, kt, li, s, lh);
+      img_row<T, D>(vf, vt, li, s, lh);
+      mma32<T>(sc, kf, qf[s]);
+      mma32<T>(dp, vf, gf[s]);
+    }
+    const bool ragged = kb + FEWQ_BK > p.Nk;                 // wave-uniform
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float pv = __builtin_amdgcn_exp2f(sc[r] * c - lse2);
+      if (ragged && kb + acc_row(r, lh) >= p.Nk) pv = 0.0f;
+      sc[r] = pv * (dp[r] - dl);                            // dS^T (the softmax scale is folded into the final store)
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> df;
+      frag_from_acc<T>(df, sc, s);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag<T> ktf;
+        img_tr<T, D>(ktf, kt, 0, s, 32 * dt, lane);
+        mma32<T>(dq[dt], ktf, df);
+      }
+    }
+  }
+  __syncthreads();
+  float* area = reinterpret_cast<float*>(smem);
+  {
+    float* mine = area + wave * 32 * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[(dt * 16 + r) * 64 + lane] = dq[dt][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll 1
+  for (int w = 1; w < FEWQ_NW; ++w) {
+    const float* theirs = area + w * 32 * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] += theirs[(dt * 16 + r) * 64 + lane];
+  }
+  T* dQp = (T*)p.dQ + (int64_t)b * p.q_bs + hd * D;
+  store_rows_T<T, D>(dQp, p.q_rs, qrow, q_ok, dq, p.scale, lh);
+}
+
 // ================================================================================================= dQ
 // Tile hand-over of the backward kernels: on the LDS-DMA path a wave's own requests (and its LDS stores) must have landed BEFORE it joins
 // the barrier — every wave reads rows that other waves requested, and a wait placed after the barrier covers only the wave's own.
@@ -2200,6 +2453,14 @@ template <typename T, int D> int launch_fwd(const AttnArgs& a, hipStream_t s) {
       return 0;
     }
   }
+  if constexpr (Img<T, D>::SWZ) {
+    static const bool no_fewq = getenv("FK_ATTN_NO_FEWQ") != nullptr;      // tuning knob
+    if (!no_fewq && a.Nq <= 32 && a.Nk >= 1024 && a.mask_kind == FK_MASK_NONE && !a.drop_thresh) {   // few queries, long context: the waves split the keys
+      allow_lds(attn_fwd_fewq_kernel, FEWQ_LDS);
+      hipLaunchKernelGGL(attn_fwd_fewq_kernel, dim3((unsigned)(a.H * a.B)), dim3(FEWQ_NW * 64), FEWQ_LDS, s, a);
+      return 0;
+    }
+  }
   dim3 grid((unsigned)(((a.Nq + NW * 32 - 1) / (NW * 32)) * a.H * a.B));
   const size_t lds = fwd_lds<T, D>();
   allow_lds(attn_fwd_kernel<T, D, NW>, lds);
@@ -2257,7 +2518,16 @@ template <typename T, int D> int launch_bwd(const AttnArgs& a, hipStream_t s) {
       return 0;
     }
   }
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), gq, dim3(NT), lds_q, s, a);
+  bool dq_done = false;
+  if constexpr (Img<T, D>::SWZ) {
+    static const bool no_fewq = getenv("FK_ATTN_NO_FEWQ") != nullptr;      // tuning knob
+    if (!no_fewq && a.Nq <= 32 && a.Nk >= 1024 && a.mask_kind == FK_MASK_NONE && !a.drop_thresh && !a.rope_table) {
+      allow_lds(attn_bwd_dq_fewq_kernel, FEWQ_LDS);                        // few queries, long context: the waves split the keys
+      hipLaunchKernelGGL(attn_bwd_dq_fewq_kernel, dim3((unsigned)(a.H * a.B)), dim3(FEWQ_NW * 64), FEWQ_LDS, s, a);
+      dq_done = true;
+    }
+  }
+  if (!dq_done) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), gq, dim3(NT), lds_q, s, a);
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D>), gk, dim3(NT), lds_kv, s, a);
   return 0;
 }

@@ -720,6 +720,32 @@ def test_attention_dense_mask_agrees_with_the_analytic_kinds(K):
         K.attn_fwd(qv.bfloat16().repeat(1, 1, 1, 2), kv.bfloat16().repeat(1, 1, 1, 2), vv.bfloat16().repeat(1, 1, 1, 2), m, q_prescaled=True)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 32, 6144, True), (1, 2, 20, 1100, False), (2, 1, 8, 1024, False), (1, 2, 32, 2500, True)])
+def test_attention_few_queries_long_context(K, case):
+    """the perceiver read-out shape (models/brainformer.py:204-215: 32 queries x 6144 keys, no mask; bf16, D = 64, Nq <= 32, Nk >= 1024):
+    the kernels whose eight waves split the KEYS and merge their partial softmax states — forward, LSE and all three gradients against
+    the oracle, with ragged key counts (a partial last tile, waves with different tile counts) and fewer than 32 queries; a spike in a
+    late key tile makes the waves' maxima differ by far."""
+    B, H, Nq, Nk, spike = case
+    D, dtype = 64, torch.bfloat16
+    qv, kv, vv, do = rnd(B, Nq, H, D, seed=1), rnd(B, Nk, H, D, seed=2), rnd(B, Nk, H, D, seed=3), rnd(B, Nq, H, D, seed=4)
+    if spike:
+        kv[:, Nk - 40] *= 6.0
+    qd, kd, vd = dev(qv, dtype), dev(kv, dtype), dev(vv, dtype)
+    o, lse = K.attn_fwd(qd, kd, vd)
+    qr, kr, vr = (q(t_, dtype).requires_grad_(True) for t_ in (qv, kv, vv))
+    oref = ref_attn(qr, kr, vr, None)
+    close(o, oref, dtype, atol16=2e-2)
+    s = (qr.transpose(1, 2) @ kr.transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
+    close(lse, torch.logsumexp(s, -1), torch.float32, atol32=3e-2, rtol32=1e-4)
+    oref.backward(q(do, dtype))
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    K.attn_bwd(qd, kd, vd, o, dev(do, dtype), lse, dq, dk, dv)
+    close(dq, qr.grad, dtype, atol16=4e-2)
+    close(dk, kr.grad, dtype, atol16=4e-2)
+    close(dv, vr.grad, dtype, atol16=4e-2)
+
+
 # ----------------------------------------------------------------------------------------------- dropout
 def drop_words(seed, step):
     return torch.tensor([seed, step], dtype=torch.int32, device="cuda")
