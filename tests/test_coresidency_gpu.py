@@ -58,3 +58,36 @@ def test_rope_kernels_keep_their_bits_beside_a_concurrent_gemm():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             assert torch.equal(out, ref), f"{name}: {int((out != ref).sum())} elements differ beside a concurrent GEMM (rep {rep})"
+
+
+def test_few_query_attention_keeps_its_bits_beside_a_concurrent_gemm():
+    """the kernels whose eight waves split the keys and merge through LDS (attn_fwd_fewq_kernel / attn_bwd_dq_fewq_kernel): their merge
+    order is fixed, so the result must not depend on what else runs — three passes beside the same occupant, bit for bit."""
+    from frankenstein_amd import kernels as K
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *s: (torch.randn(*s, device=dev, generator=g) * 0.5).bfloat16()
+    B, H, T, N, D = 8, 6, 32, 6144, 64
+    q, kv, do = rnd(B, T, H, D), rnd(B, N, 2 * H * D), rnd(B, T, H, D)
+    k, v = kv[..., : H * D].unflatten(-1, (H, D)), kv[..., H * D:].unflatten(-1, (H, D))
+    ga, gb = rnd(B * N, 320), rnd(B * N, 840)
+
+    def run():
+        o, lse = K.attn_fwd(q, k, v)
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        K.attn_bwd(q, k, v, o, do, lse, dq, dkv[..., : H * D].unflatten(-1, (H, D)), dkv[..., H * D:].unflatten(-1, (H, D)))
+        return o, lse, dq, dkv
+
+    ref = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(10):
+                K.gemm_tn(ga, gb)
+        out = run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for name, a, b in zip(("o", "lse", "dq", "dkv"), out, ref):
+            assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ beside a concurrent GEMM (rep {rep})"
