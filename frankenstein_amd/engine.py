@@ -341,25 +341,44 @@ def _attn_prescale(D: int) -> bool:
 # --------------------------------------------------------------------------------------------- dropout
 # nn.Dropout / SDPA dropout_p of the GPT-2 decoder in training mode (models/gpt2_model.py:40,64,75,85,91,129).  No mask tensor exists:
 # every application is (p, seed words, site) and the kernels regenerate keep / drop from the element index (include/franken_hip.h,
-# fk_dropout).  The seed words live on the device — [torch.initial_seed(), a step counter advanced once per forward by dropout_begin()] —
-# so a captured training step draws new masks on every replay; `site` numbers the applications within one forward.
+# fk_dropout).  The MASTER seed words live on the device — [torch.initial_seed(), a step counter advanced once per forward by
+# dropout_begin()] — so a captured training step draws new masks on every replay; `site` numbers the applications within one forward.
+# Every forward works on its own SNAPSHOT of the two words (one 8-byte device copy, captured in graphs too): a backward that runs after
+# another training-mode forward (two forwards, then (l1 + l2).backward(); a recompute) regenerates the masks ITS forward drew, like
+# torch's dropout.  No words tensor is ever replaced: a captured graph holds raw pointers to them, so a new seed is written in place.
 _DROP_WORDS: dict = {}
+_DROP_CUR: dict = {}
 _DROP_SITE = [0]
 
 
 def dropout_words(device) -> Tensor:
+    """The master [seed, step] words of `device` (int32, device memory; the same tensor for the life of the process)."""
     device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     seed = torch.initial_seed() & 0x7FFFFFFF
     ent = _DROP_WORDS.get(device)
-    if ent is None or (ent[0] != seed and not torch.cuda.is_current_stream_capturing()):
-        ent = _DROP_WORDS[device] = (seed, torch.tensor([seed, 0], dtype=torch.int32, device=device))
+    if ent is None:
+        ent = _DROP_WORDS[device] = [seed, torch.tensor([seed, 0], dtype=torch.int32, device=device)]
+    elif ent[0] != seed and not torch.cuda.is_current_stream_capturing():
+        ent[0] = seed
+        ent[1].copy_(torch.tensor([seed, 0], dtype=torch.int32))        # a new torch.manual_seed: restart the stream, in place
     return ent[1]
 
 
 def dropout_begin(device) -> None:
-    """Start of a training forward with dropout > 0: the next step's masks (step word + 1 on the device), sites numbered from 0."""
-    dropout_words(device)[1:].add_(1)
+    """Start of a training forward with dropout > 0: the next step's masks (master step word + 1 on the device), this forward's
+    snapshot of the words, sites numbered from 0."""
+    words = dropout_words(device)
+    words[1:].add_(1)
+    _DROP_CUR[words.device] = words.clone()
     _DROP_SITE[0] = 0
+
+
+def dropout_snapshot(device) -> Tensor:
+    """The words the current forward draws with (dropout_begin's snapshot; the master words before any forward began)."""
+    words = dropout_words(device)
+    return _DROP_CUR.get(words.device, words)
 
 
 def dropout_site() -> int:
@@ -372,7 +391,7 @@ def drop_spec(p: float, device, n_sites: int):
     if not p:
         return None
     assert 0.0 < p < 1.0, f"dropout p = {p}"
-    return (float(p), dropout_words(device)) + tuple(dropout_site() for _ in range(n_sites))
+    return (float(p), dropout_snapshot(device)) + tuple(dropout_site() for _ in range(n_sites))
 
 
 class Dropout(torch.autograd.Function):

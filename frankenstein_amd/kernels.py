@@ -193,13 +193,17 @@ class Mask:
         """Any boolean mask (True = attend) broadcastable to [B, H, N_q, N_k] — [N, N], [B, 1, N, N], [1, H, N, N], [B, H, N, N]: the
         reference's attention takes whatever tensor it is given and slices it as mask[..., -t_q:, -t_k:] (models/brainformer.py:160-168).
         Stored as uint8 [Bm, Hm, t_q, t_k] for the per-element path of the generic kernels (c = batch stride, q_off = head stride)."""
-        m = mask[..., mask.shape[-2] - t_q:, mask.shape[-1] - t_k:]
+        assert mask.dim() >= 2
+        m = mask[..., max(0, mask.shape[-2] - t_q):, max(0, mask.shape[-1] - t_k):]      # a size-1 axis stays whole, like the Python slice
         if m.dim() > 4:
             if any(d != 1 for d in m.shape[:-4]):
                 raise NotImplementedError(f"dense attention mask {tuple(mask.shape)}: at most [B, H, N_q, N_k]")
             m = m.reshape(m.shape[-4:])
         while m.dim() < 4:
             m = m.unsqueeze(0)
+        if m.shape[-2] not in (1, t_q) or m.shape[-1] not in (1, t_k):      # SDPA would refuse to broadcast it too
+            raise ValueError(f"attention mask {tuple(mask.shape)} does not broadcast to {t_q} queries x {t_k} keys")
+        m = m.expand(m.shape[0], m.shape[1], t_q, t_k)          # key-padding [B, 1, 1, N_k] and query-only [.., N_q, 1] forms: SDPA broadcasts them
         bm, hm = m.shape[0], m.shape[1]
         u8 = m.to(torch.uint8).contiguous()
         return Mask(MASK_DENSE, 0 if bm == 1 else hm * t_q * t_k, 0 if hm == 1 else t_q * t_k, 0, u8, None)
@@ -231,6 +235,15 @@ def _bnhd(t: Tensor):
     return t.stride(0), t.stride(1)
 
 
+def _check_dense(mask: "Mask", B: int, H: int, Nq: int, Nk: int) -> None:
+    """A dense table is read at b * c + h * q_off + q * Nk + k: its batch / head extents must be 1 (broadcast) or the call's."""
+    if mask.kind == MASK_DENSE:
+        t = mask.limits
+        assert t is not None and t.dim() == 4 and t.dtype == torch.uint8 and t.is_contiguous()
+        if t.shape[0] not in (1, B) or t.shape[1] not in (1, H) or t.shape[2] != Nq or t.shape[3] != Nk:
+            raise ValueError(f"dense attention mask {tuple(t.shape)} does not broadcast to [B={B}, H={H}, {Nq}, {Nk}]")
+
+
 def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optional[float] = None,
              out: Optional[Tensor] = None, q_prescaled: bool = False, dropout: Optional[tuple] = None) -> Tuple[Tensor, Tensor]:
     """q [B,Nq,H,D], k/v [B,Nk,H,D] (strided views ok) -> (o [B,Nq,H,D], lse [B,H,Nq] fp32).
@@ -239,6 +252,7 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Mask = NO_MASK, scale: Optio
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     assert k.shape == (B, Nk, H, D) and v.shape == (B, Nk, H, D) and q.dtype == k.dtype == v.dtype
+    _check_dense(mask, B, H, Nq, Nk)
     if out is None:
         out = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
@@ -266,6 +280,7 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     (qb, qr), (kb, kr), (vb, vr), (ob, orr) = _bnhd(q), _bnhd(k), _bnhd(v), _bnhd(o)
     assert _bnhd(dq) == (qb, qr) and _bnhd(dk) == (kb, kr) and _bnhd(dv) == (vb, vr) and _bnhd(do) == (ob, orr)
     assert do.dtype == q.dtype and dq.dtype == q.dtype
+    _check_dense(mask, B, H, Nq, Nk)
     delta = torch.empty(2 * B * H * ((Nq + 63) // 64 * 64), dtype=torch.float32, device=q.device)     # scratch: row statistics for dK/dV
     sc = scale if scale is not None else 1.0 / math.sqrt(D)
     with _timed(f"attn_bwd:{B}x{H}x{Nq}x{Nk}x{D}:m{mask.kind}"):

@@ -340,6 +340,14 @@ class FusedAdamW:
         side = E.wgrad_stream()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)      # join the weight-gradient stream before the update
+        if not any(self._touched):
+            # torch.optim.AdamW is a silent no-op when every .grad is None, and so is this; but here the usual way to get there is a
+            # gradient that did not come from an eager backward (arena.grad written by hand, a replayed graph, gradients produced before
+            # load_state_dict re-created the hooks) — say so instead of silently leaving the parameters alone.
+            import warnings
+            warnings.warn("FusedAdamW.step(): no parameter was reached by a backward since the last step, so nothing is updated; "
+                          "if the gradients were written into arena.grad directly (or by a replayed graph), call mark_touched() first",
+                          RuntimeWarning, stacklevel=2)
         self.t += 1
         for s0, s1, t in self._update_ranges():
             K.adamw_step_(a.flat[s0:s1], a.grad[s0:s1], self.m[s0:s1], self.v[s0:s1], t, g['lr'], g['betas'][0], g['betas'][1],

@@ -124,7 +124,8 @@ int fk_attn_bwd_dropout(const void* Q, const void* K, const void* V, const void*
 /* ---- dropout (nn.Dropout in training mode: models/gpt2_model.py:40,75 resid_dropout, :85,91 MLP, :129 embeddings).
  *      y[i] = (res ? res[i] : 0) + (keep(i) ? x[i] / (1 - p) : 0), n contiguous elements (multiple of 16 bytes), y may alias x.  The backward
  *      is the same call on dy without res.  keep(i) is a counter-based decision, nothing is stored:
- *        bits = mix32(mix32(hi ^ seed[0]) ^ (lo * 0x9E3779B9) ^ (seed[1] * 0x85EBCA6B + site)),  keep <=> bits >= p * 2^32,
+ *        bits = mix32(mix32(mix32(hi ^ seed[0]) + seed[1] * 0x85EBCA6B + site) ^ (lo * 0x9E3779B9)),  keep <=> bits >= p * 2^32,
+ *      (step and site go THROUGH a mixer round, so the masks of two sites or steps are not shifted copies of one another),
  *      mix32 = lowbias32 (x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16), (hi, lo) = the two words of i (for
  *      attention probabilities: hi = (b * H + h) * Nq + q, lo = k).  seed[0] = the run's seed, seed[1] = a step counter the caller advances
  *      once per forward — both read from DEVICE memory so that a captured graph draws a new mask on every replay; `site` numbers the

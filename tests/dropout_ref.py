@@ -1,5 +1,5 @@
 """Host restatement of the library's dropout decision (include/franken_hip.h, fk_dropout): numpy uint32 arithmetic, used by the GPU tests to
-predict every mask bit for bit.  keep <=> mix32(mix32(hi ^ seed) ^ (step * 0x85EBCA6B + site) ^ (lo * 0x9E3779B9)) >= p * 2^32."""
+predict every mask bit for bit.  keep <=> mix32(mix32(mix32(hi ^ seed) + step * 0x85EBCA6B + site) ^ (lo * 0x9E3779B9)) >= p * 2^32."""
 import numpy as np
 
 M32 = np.uint64(0xFFFFFFFF)
@@ -23,7 +23,7 @@ def threshold(p):
 def keep(seed, step, site, hi, lo, p):
     """hi, lo: broadcastable integer arrays (the two index words) -> boolean keep mask"""
     salt = np.uint64((int(step) * 0x85EBCA6B + int(site)) & 0xFFFFFFFF)
-    row = mix32(np.asarray(hi, dtype=np.uint64) ^ np.uint64(int(seed) & 0xFFFFFFFF)) ^ salt
+    row = mix32((mix32(np.asarray(hi, dtype=np.uint64) ^ np.uint64(int(seed) & 0xFFFFFFFF)) + salt) & M32)
     bits = mix32(row ^ ((np.asarray(lo, dtype=np.uint64) * np.uint64(0x9E3779B9)) & M32))
     return bits >= np.uint64(threshold(p))
 

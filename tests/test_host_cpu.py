@@ -384,3 +384,66 @@ def test_stream_verifier_sees_violations():
     assert any("M0 written" in e for e in vs.check_block("b", m0_late))
     unwaited = ok + ["ds_read_b128 v[100:103], %[a] offset:0"]
     assert any("not waited for" in e for e in vs.check_block("b", unwaited))
+
+
+def test_dense_mask_tables_follow_the_reference_slice_and_broadcast():
+    """Mask.from_dense on the host: the table is always [Bm, Hm, t_q, t_k] (size-1 query / key axes expanded the way SDPA broadcasts
+    them, longer masks sliced from the end like mask[..., -t_q:, -t_k:], models/brainformer.py:160-162), and the strides handed to the
+    kernel (c = batch stride, q_off = head stride) describe exactly that table — the key-padding form [B, 1, 1, N_k] used to keep a
+    256-byte table under a batch stride of 4096."""
+    from frankenstein_amd import kernels as K
+    m = K.Mask.from_dense(torch.ones(4, 1, 1, 64, dtype=torch.bool), 64, 64)
+    assert tuple(m.limits.shape) == (4, 1, 64, 64) and m.limits.is_contiguous() and (m.c, m.q_off) == (4096, 0)
+    pad = torch.rand(3, 1, 1, 10, generator=torch.Generator().manual_seed(0)) < 0.5
+    m = K.Mask.from_dense(pad, 7, 10)
+    assert torch.equal(m.limits.bool(), pad.expand(3, 1, 7, 10))
+    big = torch.rand(2, 3, 12, 15, generator=torch.Generator().manual_seed(1)) < 0.5
+    m = K.Mask.from_dense(big, 5, 9)
+    assert torch.equal(m.limits.bool(), big[..., -5:, -9:]) and (m.c, m.q_off) == (3 * 45, 45)
+    m = K.Mask.from_dense(torch.ones(6, 1, dtype=torch.bool), 6, 8)            # [N_q, 1]: one column for every key
+    assert tuple(m.limits.shape) == (1, 1, 6, 8) and (m.c, m.q_off) == (0, 0)
+    with pytest.raises(ValueError, match="does not broadcast"):
+        K.Mask.from_dense(torch.ones(2, 1, 3, 8, dtype=torch.bool), 6, 8)
+    with pytest.raises(ValueError, match="does not broadcast"):
+        K._check_dense(K.Mask.from_dense(torch.ones(2, 1, 6, 8, dtype=torch.bool), 6, 8), 4, 2, 6, 8)
+    K._check_dense(K.Mask.from_dense(torch.ones(1, 2, 6, 8, dtype=torch.bool), 6, 8), 4, 2, 6, 8)
+
+
+def test_gpt_from_pretrained_maps_a_hugging_face_state_dict(monkeypatch):
+    """GPT.from_pretrained (models/gpt2_model.py:229-284) without the network: transformers' own GPT2LMHeadModel, randomly initialised from
+    its default (gpt2, 124 M) config, stands in for the downloaded checkpoint — so the state dict has the real HF layout (Conv1D weights
+    stored [in, out], tied lm_head) — plus the two causal-mask buffers old checkpoints carry.  Checked functionally: a Conv1D computes
+    x @ W + b, the loaded nn.Linear-style weight must give the same product; embeddings / norms / biases are copied as they are."""
+    transformers = pytest.importorskip("transformers")
+    from frankenstein_amd.models import gpt2_model as g2
+    torch.manual_seed(0)
+    hf_model = transformers.GPT2LMHeadModel(transformers.GPT2Config())
+    hf_sd = dict(hf_model.state_dict())
+    hf_sd["transformer.h.0.attn.bias"] = torch.ones(1, 1, 1024, 1024, dtype=torch.bool).tril()        # skipped by the loader
+    hf_sd["transformer.h.0.attn.masked_bias"] = torch.tensor(-1e4)
+
+    class Fake:
+        def state_dict(self):
+            return hf_sd
+
+    asked = []
+    monkeypatch.setattr(transformers.GPT2LMHeadModel, "from_pretrained", classmethod(lambda cls, name: (asked.append(name), Fake())[1]))
+    m = g2.GPT.from_pretrained("gpt2", dict(dropout=0.0))
+    assert asked == ["gpt2"]
+    c = m.config
+    assert (c.n_layer, c.n_head, c.n_embd, c.block_size, c.vocab_size, c.bias, c.dropout) == (12, 12, 768, 1024, 50257, True, 0.0)
+    sd = m.state_dict()
+    assert m.lm_head.weight is m.transformer.wte.weight and torch.equal(sd["lm_head.weight"], hf_sd["transformer.wte.weight"])
+    x = torch.randn(3, 768, generator=torch.Generator().manual_seed(1))
+    for layer in (0, 11):
+        for name, xin in (("attn.c_attn", x), ("attn.c_proj", x), ("mlp.c_fc", x), ("mlp.c_proj", torch.randn(3, 3072, generator=torch.Generator().manual_seed(2)))):
+            k = f"transformer.h.{layer}.{name}"
+            want = xin @ hf_sd[k + ".weight"] + hf_sd[k + ".bias"]                       # transformers' Conv1D
+            got = torch.nn.functional.linear(xin, sd[k + ".weight"], sd[k + ".bias"])
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+        for name in ("ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias"):
+            assert torch.equal(sd[f"transformer.h.{layer}.{name}"], hf_sd[f"transformer.h.{layer}.{name}"])
+    for k in ("transformer.wte.weight", "transformer.wpe.weight", "transformer.ln_f.weight", "transformer.ln_f.bias"):
+        assert torch.equal(sd[k], hf_sd[k])
+    with pytest.raises(AssertionError):
+        g2.GPT.from_pretrained("gpt2", dict(bias=False))              # only dropout may be overridden (models/gpt2_model.py:233)

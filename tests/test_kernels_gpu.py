@@ -720,6 +720,50 @@ def test_attention_dense_mask_agrees_with_the_analytic_kinds(K):
         K.attn_fwd(qv.bfloat16().repeat(1, 1, 1, 2), kv.bfloat16().repeat(1, 1, 1, 2), vv.bfloat16().repeat(1, 1, 1, 2), m, q_prescaled=True)
 
 
+@pytest.mark.parametrize("shape", ["b11k", "11q1", "1hq1", "kk_sliced", "b1qk_long"])
+def test_attention_dense_mask_broadcast_forms(K, shape):
+    """Masks with size-1 query / key axes — the common key-padding form [B, 1, 1, N_k], a query-only [1, 1, N_q, 1], per-head rows —
+    are legal in the reference (mask[..., -t_q:, -t_k:] leaves a size-1 axis whole, SDPA broadcasts it: models/brainformer.py:160-168);
+    a mask longer than the call is sliced from the END of both axes.  A batch / head extent that is neither 1 nor the call's is refused."""
+    B, H, Nq, Nk, D = 3, 2, 70, 150, 32
+    g = torch.Generator().manual_seed(11)
+    if shape == "b11k":
+        mt = torch.rand(B, 1, 1, Nk, generator=g) < 0.6
+        mt[..., 0] = True
+    elif shape == "11q1":
+        mt = torch.ones(1, 1, Nq, 1, dtype=torch.bool)
+    elif shape == "1hq1":
+        mt = torch.ones(1, H, Nq, 1, dtype=torch.bool)
+    elif shape == "kk_sliced":
+        mt = torch.rand(Nk + 20, Nk + 9, generator=g) < 0.5
+        mt[:, -1] = True
+    else:
+        mt = torch.rand(B, 1, Nq + 5, Nk + 3, generator=g) < 0.5
+        mt[..., -1] = True
+    m = K.Mask.from_dense(mt.cuda(), Nq, Nk)
+    assert m.limits.shape[-2:] == (Nq, Nk) and m.limits.is_contiguous()
+    full = mt[..., max(0, mt.shape[-2] - Nq):, max(0, mt.shape[-1] - Nk):]
+    qv, kv, vv, do = rnd(B, Nq, H, D, seed=1), rnd(B, Nk, H, D, seed=2), rnd(B, Nk, H, D, seed=3), rnd(B, Nq, H, D, seed=4)
+    qd, kd, vd = (dev(t_, torch.float32) for t_ in (qv, kv, vv))
+    o, lse = K.attn_fwd(qd, kd, vd, m)
+    qr, kr, vr = (q(t_, torch.float32).requires_grad_(True) for t_ in (qv, kv, vv))
+    oref = ref_attn(qr, kr, vr, full)
+    close(o, oref, torch.float32, atol32=2e-5, atol16=2e-2)
+    oref.backward(q(do, torch.float32))
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    K.attn_bwd(qd, kd, vd, o, dev(do, torch.float32), lse, dq, dk, dv, m)
+    close(dq, qr.grad, torch.float32, atol32=5e-5, atol16=4e-2)
+    close(dk, kr.grad, torch.float32, atol32=5e-5, atol16=4e-2)
+    close(dv, vr.grad, torch.float32, atol32=5e-5, atol16=4e-2)
+    bad = K.Mask.from_dense(torch.ones(2, 1, Nq, Nk, dtype=torch.bool, device="cuda"), Nq, Nk)      # two samples' masks for a batch of three
+    with pytest.raises(ValueError, match="does not broadcast"):
+        K.attn_fwd(qd, kd, vd, bad)
+    with pytest.raises(ValueError, match="does not broadcast"):
+        K.attn_bwd(qd, kd, vd, o, dev(do, torch.float32), lse, dq, dk, dv, bad)
+    with pytest.raises(ValueError, match="does not broadcast"):
+        K.Mask.from_dense(torch.ones(B, 1, 7, Nk, dtype=torch.bool, device="cuda"), Nq, Nk)
+
+
 @pytest.mark.parametrize("case", [(2, 3, 32, 6144, True), (1, 2, 20, 1100, False), (2, 1, 8, 1024, False), (1, 2, 32, 2500, True)])
 def test_attention_few_queries_long_context(K, case):
     """the perceiver read-out shape (models/brainformer.py:204-215: 32 queries x 6144 keys, no mask; bf16, D = 64, Nq <= 32, Nk >= 1024):

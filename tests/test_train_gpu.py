@@ -159,3 +159,23 @@ def test_fused_adamw_skips_parameters_without_gradient_like_torch():
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), rtol=2e-6, atol=2e-7, err_msg=k)
     sd = opt.state_dict()
     assert sd["lag"] == [0, 3, 0]
+
+
+def test_fused_adamw_step_without_any_reached_parameter_warns_and_mark_touched_steps():
+    """A gradient written into arena.grad directly is invisible to the post-accumulate-grad hooks: step() then leaves every parameter
+    alone like torch.optim.AdamW with all-None grads — but says so (RuntimeWarning); after mark_touched() the same gradient is applied."""
+    import warnings
+    from frankenstein_amd.utils import train_utils as tu
+    m = _TwoHeads().cuda()
+    opt = tu.FusedAdamW(m, lr=1e-2, weight_decay=0.0, grad_clip=None)
+    before = opt.arena.flat.clone()
+    opt.arena.grad.fill_(0.5)
+    with pytest.warns(RuntimeWarning, match="mark_touched"):
+        opt.step()
+    assert torch.equal(opt.arena.flat, before)
+    opt.arena.grad.fill_(0.5)
+    opt.mark_touched()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        opt.step()
+    assert float((opt.arena.flat - before).abs().max()) > 1e-3
