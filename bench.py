@@ -130,15 +130,24 @@ def cpu_baseline(steps=2):
             "samples": samples}
 
 
+def _latest_profile(suffix):
+    """newest profiles/rNN_<suffix> (the committed rocprofv3 counter passes are named per round); None if there is none"""
+    found = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{suffix}"))
+    return found[-1] if found else None
+
+
 def mfma_util_pmc():
-    """MFMA-pipe busy fraction of the whole step and of the roofline kernels from the committed rocprofv3 counter pass
-    (profiles/r03_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)); None if absent."""
+    """MFMA-pipe busy fraction of the whole step and of the roofline kernels from the newest COMMITTED rocprofv3 counter pass
+    (profiles/rNN_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)) — builder-run evidence, not measured
+    in this run (counters need rocprofv3 around the process); `source` says which file.  None if absent."""
     try:
-        pm = json.load(open(ROOT / "profiles" / "r03_pmc_mfma_util.json"))
+        path = _latest_profile("pmc_mfma_util.json")
+        pm = json.load(open(path))
         ks = pm["kernels"]
         pick = lambda frag: next((round(v["mfma_util_pct"], 1) for k, v in ks.items() if frag in k), None)
         return {"whole_step_pct": round(pm["whole_trace"]["mfma_util_pct"], 1), "attn_bwd_dkdv_pct": pick("attn_bwd_dkdv"),
-                "attn_bwd_dq_pct": pick("attn_bwd_dq"), "executed_mfma_tflops": round(pm["whole_trace"]["mfma_tflops"], 1)}
+                "attn_bwd_dq_pct": pick("attn_bwd_dq"), "executed_mfma_tflops": round(pm["whole_trace"]["mfma_tflops"], 1),
+                "source": f"profiles/{path.name}, builder-run rocprofv3 --pmc pass over one benchmark step (not measured in this run)"}
     except Exception:
         return None
 
@@ -244,13 +253,51 @@ def dp_report(gs, arena, dev, steps):
             "bucket_mb": [round((e - s0) * 4 / 2 ** 20, 2) for s0, e, _ in gs.buckets], "world": gs.world}
 
 
-def parity_block():
-    """bf16-vs-reference numbers at the benchmarked shape, measured by tests/test_models_gpu.py::test_cfg2_b1_bf16_vs_reference and
-    committed under profiles/ (None when that file is absent)."""
+def parity_live(dev):
+    """bf16-vs-reference numbers at the benchmarked shape, MEASURED IN THIS RUN (rank 0, after the timed region): cfg2 at B = 1 in the
+    benchmark's precision, forward + backward, against the reference's own fp32 CPU run stored in tests/golden/cfg2_b1.npz /
+    cfg2_b1_samples.npz (loss, predictions, six encoder rows, 256 evenly spaced samples of every gradient; produced by
+    tests/golden/make_golden.py from /root/reference).  Same quantities and bounds as tests/test_models_gpu.py::
+    test_cfg2_b1_bf16_vs_reference.  None when the fixtures are absent."""
+    import numpy as np
+    from frankenstein_amd import synth
     try:
-        return json.load(open(ROOT / "profiles" / "r03_parity_cfg2_bf16.json"))
+        z = np.load(ROOT / "tests" / "golden" / "cfg2_b1.npz", allow_pickle=False)
+        zs = np.load(ROOT / "tests" / "golden" / "cfg2_b1_samples.npz", allow_pickle=False)
     except Exception:
         return None
+    m, _ = cfg2_model("bf16", "l1")
+    init_weights(m)
+    m.to(dev)
+    x = torch.from_numpy(synth.make_inputs(1, 600, 256)).to(dev)
+    tgt = torch.from_numpy(synth.make_motion_targets(1, 32, 128)).to(dev)
+    loss, pred = m(x, tgt)
+    with torch.no_grad():
+        ctx = m.encoder(x)
+    loss.backward()
+    rel = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+    perr = float(np.abs(pred.float().detach().cpu().numpy() - z["pred"]).max())
+    eerr = float(np.abs(ctx[0, [0, 1, 255, 256, 3071, 6143]].float().cpu().numpy() - z["enc_rows"]).max())
+    want = {str(n): r for n, r in zip(zs["grad_names"], zs["grad_samples"])}
+    cos, seen = {}, set()
+    for k, p_ in m.named_parameters():
+        if id(p_) in seen or k not in want:
+            continue
+        seen.add(id(p_))
+        a = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).detach().double().flatten().cpu().numpy()
+        idx = np.arange(a.size) if a.size <= 256 else (np.arange(256, dtype=np.int64) * a.size) // 256
+        r = np.zeros(256)
+        r[: idx.size] = a[idx]
+        den = float(np.linalg.norm(r) * np.linalg.norm(want[k]))
+        cos[k] = float(np.dot(r, want[k]) / den) if den > 0 else 1.0
+    worst = min(cos, key=cos.get)
+    return {"source": "measured in this run against tests/golden/cfg2_b1*.npz (the reference's fp32 CPU run)",
+            "shape": "cfg2 at B=1 (6L d=384 6x64 heads, N=6144), bf16 vs reference fp32 CPU, forward + backward",
+            "loss_rel_err": rel, "pred_max_abs_err": perr, "pred_max_abs": float(np.abs(z["pred"]).max()), "enc_rows_max_abs_err": eerr,
+            "enc_rows_max_abs": float(np.abs(z["enc_rows"]).max()), "grad_cosine_min": cos[worst], "grad_cosine_min_param": worst,
+            "grad_cosine_median": float(np.median(list(cos.values()))), "n_params": len(cos),
+            "bounds": {"loss_rel_err": 1e-2, "pred_max_abs_err": 5e-2, "grad_cosine_min": 0.99},
+            "within_bounds": bool(rel < 1e-2 and perr < 5e-2 and cos[worst] >= 0.99)}
 
 
 def main():
@@ -263,6 +310,7 @@ def main():
     ap.add_argument("--head", default="l1", choices=["l1", "ce"], help="l1: the headline workload; ce: cfg2's CE-head variant (25 tokens, V = 50257)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the live bf16-vs-reference check at B = 1 (tests/golden/cfg2_b1*.npz)")
     ap.add_argument("--all-timers", action="store_true", help="HIP-event timing of every kernel family (default: the roofline kernel family only)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous only, gloo on the CPU (no GPU work)")
     args = ap.parse_args()
@@ -354,16 +402,19 @@ def main():
             bwd = name.startswith("attn_bwd")
             fl = attn_flops(B, 6, 6144, 6144, 64, 256, bwd)
             avg_s = tot / cnt / 1e3
-            traffic = None
-            try:   # HBM bytes per call from the committed rocprofv3 PMC passes (FETCH_SIZE x2 corrected + WRITE_SIZE)
-                pm = json.load(open(ROOT / "profiles" / "r03_pmc_traffic.json"))
+            traffic, traffic_src = None, None
+            try:   # HBM bytes per call from the newest committed rocprofv3 PMC passes (FETCH_SIZE x2 corrected + WRITE_SIZE)
+                tpath = _latest_profile("pmc_traffic.json")
+                pm = json.load(open(tpath))
                 traffic = pm["fk_attn_bwd_bytes_per_call"] if bwd else None
+                traffic_src = f"profiles/{tpath.name}, builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (not measured in this run)"
             except Exception:
                 pass
             roof = {"kernel": "fk_attn_bwd (attn_bwd_dq [+ delta] and attn_bwd_dkdv launches of one call)" if bwd else "fk_attn_fwd",
                     "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(fl / avg_s / MFMA_PEAK_BF16, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per call, rocprofv3 PMC (profiles/r03_pmc_traffic.json); algorithmic bytes 1.21e9 with every tensor counted once; the two deterministic kernels (dQ, dK/dV) each have to read Q, K, V, dO, so their compulsory traffic is 1.82e9",
+                    "traffic_source": traffic_src,
+                    "traffic_note": "HBM bytes per call; algorithmic bytes 1.21e9 with every tensor counted once; the two deterministic kernels (dQ, dK/dV) each have to read Q, K, V, dO, so their compulsory traffic is 1.82e9",
                     "flops_per_launch": fl, "avg_launch_ms": round(avg_s * 1e3, 3)}
         out = {
             "metric": "neural frames/sec (train fwd+bwd+AdamW, whole job)", "value": round(value, 1), "unit": "frames/s",
@@ -383,8 +434,9 @@ def main():
             "dp": dp, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS") if world > 1 else None,
             "kernel_families": detail,
             "loss": round(float(loss), 5),
-            "parity": parity_block(),
         }
+        if args.dtype == "bf16" and not args.no_parity:
+            out["parity"] = parity_live(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

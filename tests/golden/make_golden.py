@@ -473,9 +473,70 @@ def cfg2_batch_golden(B=3):
          grad_names=gn, grad_rows=gr, grad_samples=sr)
 
 
+def _cfg2_reference_model():
+    bf, g2, tu = import_reference()
+    enc = bf.MAEConfig(window_size=600, n_electrodes=256, patch_size=25, dim=384, n_layers=6, head_dim=64,
+                       hidden_dim=1536, n_heads=6, n_kv_heads=6)
+    cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=384, n_layers=2, head_dim=64,
+                    hidden_dim=768, n_heads=6, n_kv_heads=6)
+    m = bf.BrainFormer(cfg).float()
+    load_synth(m)
+    return m
+
+
+ENC_ROWS = [0, 1, 255, 256, 3071, 6143]
+
+
+def cfg2_b32_fwd_golden(B=32):
+    """The BENCHMARKED batch through the reference: cfg2 (brainformer-small, N = 6144, L1 head), B = 32, forward only under
+    torch.no_grad() — loss, the [32, 32, 128] predictions and six encoder rows of every sample.  One call of the reference's forward on
+    the whole batch (models/brainformer.py:532-558); the address space is capped so that a host without the memory for it fails with a
+    Python error instead of being killed."""
+    import resource
+    resource.setrlimit(resource.RLIMIT_AS, (56 << 30, 56 << 30))
+    m = _cfg2_reference_model()
+    x = torch.from_numpy(synth.make_inputs(B, 600, 256))
+    tgt = torch.from_numpy(synth.make_motion_targets(B, 32, 128))
+    with torch.no_grad():
+        loss, pred = m(x, tgt)
+        ctx = m.encoder(x)
+    save(f"cfg2_b{B}_fwd", loss=np.array(float(loss)), pred=pred.numpy(), enc_rows=ctx[:, ENC_ROWS].numpy(),
+         note=np.array("reference forward, one call at B = 32, torch.no_grad(), CPU fp32"))
+
+
+def cfg2_b8_grad_golden(B=8, MB=2):
+    """cfg2 at B = 8 WITH gradients.  The reference's dense-mask attention keeps ~15 GB of fp32 scores per sample alive for the backward,
+    so a B = 8 backward does not fit this container: the gradient is produced by the reference's OWN modules over four micro-batches of
+    two samples, each loss scaled by MB / B before backward() so that autograd's accumulation gives the gradient of the B = 8 mean
+    loss (the L1 loss is a mean over equally sized samples; this is stated in the fixture's `note`).  Loss = mean of the four losses,
+    pred / encoder rows concatenated."""
+    m = _cfg2_reference_model()
+    from tests import cases as TC
+    x = torch.from_numpy(synth.make_inputs(B, 600, 256))
+    tgt = torch.from_numpy(synth.make_motion_targets(B, 32, 128))
+    losses, preds, rows = [], [], []
+    for i in range(0, B, MB):
+        loss, pred = m(x[i:i + MB], tgt[i:i + MB])
+        (loss * (MB / B)).backward()
+        losses.append(float(loss))
+        preds.append(pred.detach())
+        with torch.no_grad():
+            rows.append(m.encoder(x[i:i + MB])[:, ENC_ROWS])
+    gn, gr = summarize(grads_of(m))
+    sn, sr = TC.sample_rows(grads_of(m))
+    save(f"cfg2_b{B}_grad", loss=np.array(float(np.mean(losses))), micro_losses=np.array(losses), pred=torch.cat(preds).numpy(),
+         enc_rows=torch.cat(rows).numpy(), grad_names=gn, grad_rows=gr, grad_samples=sr,
+         note=np.array(f"reference modules, {B // MB} micro-batches of {MB} samples, each loss * {MB}/{B} before backward() (autograd accumulation) "
+                       f"= gradient of the B = {B} mean L1 loss; CPU fp32"))
+
+
 if __name__ == "__main__":
     if os.environ.get("FK_GOLDEN_ONLY") == "cfg2_b3":
         cfg2_batch_golden()
+    elif os.environ.get("FK_GOLDEN_ONLY") == "cfg2_b32_fwd":
+        cfg2_b32_fwd_golden()
+    elif os.environ.get("FK_GOLDEN_ONLY") == "cfg2_b8_grad":
+        cfg2_b8_grad_golden()
     elif os.environ.get("FK_GOLDEN_ONLY") == "pipeline":
         pipeline_golden()
     elif os.environ.get("FK_GOLDEN_ONLY") == "vq_conv_small":
@@ -488,3 +549,5 @@ if __name__ == "__main__":
         vq_golden()
         accum_golden()
         cfg2_batch_golden()
+        cfg2_b8_grad_golden()
+        cfg2_b32_fwd_golden()

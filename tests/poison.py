@@ -1,6 +1,8 @@
-"""Opt-in memory checks for the GPU suite (FK_TEST_POISON=1): every buffer the product allocates through torch.empty / empty_like / zeros in
-frankenstein_amd.kernels, .engine, .models.brainformer, .models.gpt2_model and .utils.data_utils (outputs, workspaces, saved activations,
-key/value caches) is carved out of a larger allocation with a
+"""Memory checks for the GPU suite (on by default where a GPU is present; FK_TEST_POISON=0 switches them off): every buffer the product
+allocates through torch.empty / empty_like / zeros / zeros_like in frankenstein_amd.kernels, .engine, every module of .models and
+.utils.train_utils / .utils.data_utils (outputs, workspaces, saved activations, key/value caches, the parameter / gradient / moment arenas)
+— and every output buffer the kernel-level tests allocate themselves (dq / dk / dv, o, GEMM out=: the test modules' `torch` name is guarded
+too) — is carved out of a larger allocation with a
 4-KiB guard band on both sides, and `empty` buffers are filled with 0xFF bytes (NaN in fp32 / bf16, -1 in integers) instead of whatever the
 caching allocator hands back.  After each test the bands are compared with their pattern: a kernel that writes past either end of its
 output fails the test that ran it, and a kernel that leaves part of an output unwritten shows up as NaN in whatever consumes it —
@@ -36,6 +38,11 @@ class _Proxy:
         if kw or not x.is_contiguous():
             return torch.empty_like(x, **kw)
         return self._t.alloc(tuple(x.shape), x.dtype, x.device, poison=True, fallback=lambda: torch.empty_like(x))
+
+    def zeros_like(self, x, **kw):
+        if kw or not x.is_contiguous():
+            return torch.zeros_like(x, **kw)
+        return self._t.alloc(tuple(x.shape), x.dtype, x.device, poison=False, fallback=lambda: torch.zeros_like(x))
 
 
 class Tracker:
@@ -75,12 +82,21 @@ class Tracker:
         return bad
 
 
+PRODUCT_MODULES = ("frankenstein_amd.kernels", "frankenstein_amd.engine", "frankenstein_amd.models.brainformer", "frankenstein_amd.models.gpt2_model",
+                   "frankenstein_amd.models.simple_mae", "frankenstein_amd.models.vq_brain", "frankenstein_amd.models.notebook_models",
+                   "frankenstein_amd.utils.train_utils", "frankenstein_amd.utils.data_utils")
+TEST_MODULES = ("tests.test_kernels_gpu", "tests.test_coresidency_gpu")        # kernel-level tests allocate their own outputs
+
+
 def install():
-    from frankenstein_amd import engine, kernels
-    from frankenstein_amd.models import brainformer, gpt2_model
-    from frankenstein_amd.utils import data_utils
+    import importlib
+    import sys
     tracker = Tracker()
     proxy = _Proxy(tracker)
-    for mod in (kernels, engine, brainformer, gpt2_model, data_utils):
-        mod.torch = proxy
+    for name in PRODUCT_MODULES:
+        importlib.import_module(name).torch = proxy
+    for name in TEST_MODULES:
+        mod = sys.modules.get(name)                      # only those the session collected
+        if mod is not None and getattr(mod, "torch", None) is torch:
+            mod.torch = proxy
     return tracker

@@ -165,6 +165,27 @@ def test_cfg2_b3(golden):
         np.testing.assert_allclose(r, want[n], rtol=2e-3, atol=2e-4, err_msg=n)
 
 
+def test_cfg2_b32_and_b8_fixtures_on_sample_subsets(golden):
+    """The B = 32 forward fixture and the B = 8 gradient fixture (both produced by the reference, tests/golden/make_golden.py) against the
+    oracle on SUBSETS the CPU suite can afford: the last two samples of the B = 32 batch (samples are independent through the forward,
+    so their predictions / encoder rows must match row for row) and the last micro-batch of the B = 8 run (its loss as the reference
+    logged it)."""
+    z = golden("cfg2_b32_fwd")
+    cfg, x, tgt = C.cfg2(32)
+    sd = C.state(R.brainformer_shapes(cfg, "to_motion"))
+    with torch.no_grad():
+        _, pred = R.brainformer_l1(sd, x[30:], tgt[30:], cfg)
+    np.testing.assert_allclose(pred.numpy(), z["pred"][30:], atol=1e-4)
+    assert abs(float((torch.from_numpy(z["pred"]) - tgt).abs().mean()) - float(z["loss"])) < 1e-6      # the loss IS the batch mean of |pred - target|
+    z = golden("cfg2_b8_grad")
+    cfg, x, tgt = C.cfg2(8)
+    with torch.no_grad():
+        loss, pred = R.brainformer_l1(sd, x[6:], tgt[6:], cfg)
+    assert abs(float(loss) - float(z["micro_losses"][3])) < 1e-5
+    np.testing.assert_allclose(pred.numpy(), z["pred"][6:], atol=1e-4)
+    assert abs(float(np.mean(z["micro_losses"])) - float(z["loss"])) < 1e-7
+
+
 def test_cfg2_b1_gradient_samples_and_ce_head(golden):
     """The two fixtures added for the benchmarked shape: evenly spaced samples of every gradient of the L1-head run, and the
     CE-head variant (notebook class, 25 output tokens, V = 50257) — the oracle reproduces both."""
