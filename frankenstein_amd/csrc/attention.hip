@@ -271,6 +271,9 @@ FK_DEV unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
+#ifndef FK_NT_STORES_ATTN
+#define FK_NT_STORES_ATTN 0      // 1: O / dQ / dK / dV rows stored non-temporal (written once; the launch keeps re-reading K / V or Q / dO out of L2)
+#endif
 template <typename T, int D>
 FK_DEV void store_rows_T(T* base, int64_t rs, int row, bool row_ok, const f32x16 (&acc)[AT<T, D>::DT], float mul, int lh) {
   if constexpr (sizeof(T) == 2 && D % 16 == 0) {
@@ -286,7 +289,7 @@ FK_DEV void store_rows_T(T* base, int64_t rs, int row, bool row_ok, const f32x16
           unsigned y0 = pack_bf16x2(acc[dt][4 * g + 4] * mul, acc[dt][4 * g + 5] * mul), y1 = pack_bf16x2(acc[dt][4 * g + 6] * mul, acc[dt][4 * g + 7] * mul);
           swap_halves(x0, y0);
           swap_halves(x1, y1);
-          if (row_ok) *reinterpret_cast<u32x4*>(rowp + dt * 32 + 8 * (g + lh)) = u32x4{x0, x1, y0, y1};
+          if (row_ok) fk_st<FK_NT_STORES_ATTN != 0>(reinterpret_cast<u32x4*>(rowp + dt * 32 + 8 * (g + lh)), u32x4{x0, x1, y0, y1});
         }
       }
     return;
@@ -344,7 +347,7 @@ FK_DEV void store_rows_T_rope(T* base, int64_t rs, int row, bool row_ok, const f
           unsigned x0 = pack_bf16x2(ox[0], ox[1]), x1 = pack_bf16x2(ox[2], ox[3]), y0 = pack_bf16x2(oy[0], oy[1]), y1 = pack_bf16x2(oy[2], oy[3]);
           swap_halves(x0, y0);
           swap_halves(x1, y1);
-          if (row_ok) *reinterpret_cast<u32x4*>(rowp + dt * 32 + 8 * (2 * gp + lh)) = u32x4{x0, x1, y0, y1};
+          if (row_ok) fk_st<FK_NT_STORES_ATTN != 0>(reinterpret_cast<u32x4*>(rowp + dt * 32 + 8 * (2 * gp + lh)), u32x4{x0, x1, y0, y1});
         }
       }
     return;
@@ -1749,12 +1752,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_asm_kernel(AttnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
+  // Steps outside the unrolled steady loop (the first lean step, the at most three that align the tile counter to the loop, the tail and
+  // the drain) run ONE block per kind for any ring slot: the LDS addresses are moved to the slots here (eight adds per step).  With a
+  // switch over four per-slot blocks hipcc moved the carried scores and an accumulator through scratch around every such step
+  // (88 bytes per lane, 208 MB written and read per cfg2 call).
 #define FK_FWD_STEP(KIND, tt)                                                                                                       \
-  switch ((tt) & 3) {                                                                                                               \
-    case 0: fwd_##KIND##_asm_slot0(o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw); break; \
-    case 1: fwd_##KIND##_asm_slot1(o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw); break; \
-    case 2: fwd_##KIND##_asm_slot2(o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw); break; \
-    default: fwd_##KIND##_asm_slot3(o[0], o[1], sc1, l, rmax, qf, aq, va0, va1, vo, k_base((tt) + 2), v_base((tt) + 2), ldsw); break; \
+  {                                                                                                                                 \
+    const unsigned so_ = (unsigned)((tt) & 3) * (unsigned)IMG, sp_ = (unsigned)(((tt) + 3) & 3) * (unsigned)IMG;                    \
+    const unsigned aqs_[4] = {aq[0] + so_, aq[1] + so_, aq[2] + so_, aq[3] + so_};                                                  \
+    fwd_##KIND##_asm_gen(o[0], o[1], sc1, l, rmax, qf, aqs_, va0 + so_, va1 + so_, va0 + sp_, va1 + sp_, vo, k_base((tt) + 2),      \
+                         v_base((tt) + 2), ldsw + (unsigned)(((tt) + 2) & 3) * (unsigned)IMG);                                      \
   }
 
   int* flag = reinterpret_cast<int*>(smem + 2 * NS * IMG);
@@ -1776,9 +1783,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_asm_kernel(AttnArgs p) {
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= a;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc1[r] = 0.0f;
-      FK_FWD_STEP(first, t)
+      FK_FWD_STEP(first, t)                                    // sc1 is an output of the first step (early-clobber, pinned): nothing to initialise
       for (++t; t < ntiles && (t & 3) != 0; ++t) { FK_FWD_STEP(steady, t) }
       // steady state without a switch (hipcc then keeps every operand in one place across the four step variants).  Told here that
       // nothing of ITS memory traffic is pending (spill stores of the classic phase are vector-memory operations): otherwise its wait-count

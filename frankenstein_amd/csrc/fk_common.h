@@ -143,7 +143,9 @@ FK_DEV float wave_max(float v) {
 
 // ------------------------------------------------------------------------------------------------
 // dropout: a counter-based keep / drop decision per element (no mask is ever stored: the backward regenerates it).
-//   bits(hi, lo) = mix32(mix32(hi ^ seed) ^ (lo * 0x9E3779B9) ^ (step * 0x85EBCA6B + site)),   keep <=> bits >= p * 2^32
+//   bits(hi, lo) = mix32(mix32(mix32(hi ^ seed) + step * 0x85EBCA6B + site) ^ (lo * 0x9E3779B9)),   keep <=> bits >= p * 2^32
+// (step and site pass through a mixer round of their own: XORed in behind the first round they made the masks of neighbouring sites
+// and steps index-shifted copies of one sequence, lo -> lo +- const).
 // mix32 = the "lowbias32" integer finaliser.  seed / step live in DEVICE memory (seed_ptr[0..1]; the step word is advanced by the host
 // framework once per forward, inside a captured graph too), `site` numbers the dropout applications of one forward.  Elementwise: hi =
 // index >> 32, lo = index; attention probabilities: hi = (b * H + h) * Nq + q, lo = key.  This is the library's own stream, restated in
@@ -156,8 +158,16 @@ struct DropKey { unsigned seed, salt, thresh; };
 FK_DEV DropKey drop_key(const unsigned* seed_ptr, unsigned site, unsigned thresh) {
   return DropKey{seed_ptr[0], seed_ptr[1] * 0x85EBCA6Bu + site, thresh};
 }
-FK_DEV unsigned drop_row(const DropKey& k, unsigned hi) { return fk_mix32(hi ^ k.seed) ^ k.salt; }
+FK_DEV unsigned drop_row(const DropKey& k, unsigned hi) { return fk_mix32(fk_mix32(hi ^ k.seed) + k.salt); }
 FK_DEV bool drop_keep(const DropKey& k, unsigned row, unsigned lo) { return fk_mix32(row ^ (lo * 0x9E3779B9u)) >= k.thresh; }
+
+// Streaming output stores.  A line written once and not read again by the same launch can be stored non-temporal (global_store ... nt:
+// the L2 treats it as a streaming request), so that it does not push the operand panels the launch keeps re-reading out of the XCD's
+// 4-MiB L2 (with plain stores the up-projection fetched its 151-MB activation operand 6 times).
+template <bool NT, typename V> FK_DEV void fk_st(V* q, const V& v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, q);
+  else *q = v;
+}
 
 // XCD-aware block remap (bijective for any grid size): blocks b and b+8 share an XCD (round-robin
 // dispatch), so give each XCD a contiguous chunk of logical tile ids -> neighbouring tiles share L2.

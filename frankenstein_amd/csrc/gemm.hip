@@ -40,6 +40,14 @@ struct NtArgs {
   int rope_qcols; int64_t rope_qoff;
 };
 
+// Output stores of the epilogue sweep: every line is written once and not read again by this launch.
+#ifndef FK_NT_STORES_GEMM
+#define FK_NT_STORES_GEMM 1      // 0: plain stores; 1 (default, -0.4 ms per cfg2 step): all fused-epilogue outputs non-temporal; 2: only the large ones (SwiGLU forward / backward, QKV + RoPE)
+#endif
+template <int EPI, typename V> FK_DEV void st_out(V* q, const V& v) {
+  fk_st<(FK_NT_STORES_GEMM == 1) || (FK_NT_STORES_GEMM == 2 && EPI >= 1)>(q, v);
+}
+
 // sigmoid: the throughput (bf16) mode uses the hardware reciprocal (1 ulp), the fp32 parity mode an exact division
 template <typename T> FK_DEV float sigmoid_f(float x) {
   if constexpr (sizeof(T) == 2) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
@@ -239,8 +247,8 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
               bf16x8 o0, o1;
 #pragma unroll
               for (int e = 0; e < 8; ++e) { o0[e] = (bf16_t)ov[e]; o1[e] = (bf16_t)ov[8 + e]; }
-              *reinterpret_cast<bf16x8*>(dp) = o0;
-              *reinterpret_cast<bf16x8*>(dp + 8) = o1;
+              st_out<EPI>(reinterpret_cast<bf16x8*>(dp), o0);
+              st_out<EPI>(reinterpret_cast<bf16x8*>(dp + 8), o1);
             } else {
 #pragma unroll
               for (int q4 = 0; q4 < 4; ++q4)
@@ -253,7 +261,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
             bf16x8 o8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x8*>(cp) = o8;
+            st_out<EPI>(reinterpret_cast<bf16x8*>(cp), o8);
           } else {
             *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -269,7 +277,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
                 bf16x4 g4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g4[e] = (bf16_t)gq[e];
-                *reinterpret_cast<bf16x4*>(gp) = g4;
+                st_out<EPI>(reinterpret_cast<bf16x4*>(gp), g4);
               } else {
                 *reinterpret_cast<f32x4*>(gp) = f32x4{gq[0], gq[1], gq[2], gq[3]};
               }

@@ -10,6 +10,9 @@
 
 namespace {
 
+#ifndef FK_NT_STORES_NORM
+#define FK_NT_STORES_NORM 0
+#endif
 template <typename T> struct VecIO;
 template <> struct VecIO<bf16_t> {
   static constexpr int N = 8;
@@ -22,7 +25,7 @@ template <> struct VecIO<bf16_t> {
     bf16x8 a;
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
-    *reinterpret_cast<bf16x8*>(p) = a;
+    fk_st<FK_NT_STORES_NORM != 0>(reinterpret_cast<bf16x8*>(p), a);
   }
 };
 template <> struct VecIO<float> {

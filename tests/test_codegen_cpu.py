@@ -3,20 +3,20 @@
 The generated attention streams (csrc/attn_*_asm.inc) name their temporaries as clobbers and leave accumulators, fragments and
 addresses to hipcc; the ring-buffered GEMMs are written for two waves per SIMD.  A compiler update that spills inside a matrix loop or
 needs more than 256 registers would only show up as a slow benchmark: this test holds the device code of attention.hip and gemm.hip to
-the bounds DESIGN.md documents (tools/kernel_resources.py prints the whole table).  The LDS budgets are static_asserts in the sources."""
+the bounds DESIGN.md documents, and every source of the library to the no-packed-fp32-half-swap rule (tools/kernel_resources.py prints the whole table).  The LDS budgets are static_asserts in the sources."""
 import pytest
 
 from tools import kernel_resources as KR
 
 # kernel-name fragment -> (max VGPRs, min waves/SIMD, max scratch bytes per lane, scratch instructions allowed inside ANY loop that holds MFMAs).
-# In every kernel the hot loop (the innermost loop with the most MFMAs) must be free of scratch traffic.  attn_fwd_asm_kernel is the one
-# kernel with spill traffic inside (cold) loops: the classic-softmax phase and the at most three steps that align the tile counter to the
-# four-step steady loop move the 16 carried scores through scratch (88 bytes per lane; it is what the forward's WRITE_SIZE of 2.3x its output was: 36864 waves x 5.6 KB); the steady loop itself (64 MFMAs per trip) has none.
+# In every kernel the hot loop (the innermost loop with the most MFMAs) must be free of scratch traffic.  attn_fwd_asm_kernel used to be the
+# one kernel with spill traffic inside (cold) loops (88 bytes per lane: what the forward's WRITE_SIZE of 2.3x its output was); since round 4
+# its steps outside the steady loop are single any-slot blocks instead of a switch over four, and it has no scratch at all.
 BOUNDS = {
     "attn_bwd_dq_asm_kernel": (256, 2, 0, 0),
     "attn_bwd_dkdv_asm_kernel": (256, 2, 20, 0),
     "attn_bwd_dkdvw_asm_kernel": (448, 1, 0, 0),          # one wave per SIMD by design: 245 VGPRs + 192 AGPRs (accumulators, K / V fragments)
-    "attn_fwd_asm_kernel": (256, 2, 96, 40),
+    "attn_fwd_asm_kernel": (256, 2, 0, 0),
     "attn_fwd_ps_kernel": (128, 4, 0, 0),
     "attn_bwd_dq_ps_kernel": (256, 2, 0, 0),
     "attn_bwd_dkdv_ps_kernel": (256, 2, 0, 0),
@@ -76,8 +76,11 @@ def test_no_compiler_packed_fp32_with_half_swaps(table):
     wrong low-half results in lanes 48-63 beside a co-resident GEMM.  The build switches the vectorizer off; hand-written
     f32x2 arithmetic (no half-swaps) stays."""
     import re
+    from pathlib import Path
     from frankenstein_amd import build as B
     assert "-fno-slp-vectorize" in B.FLAGS
-    for asm in {str(r["_asm"]) for r in table.values()}:
+    asms = {str(r["_asm"]) for r in table.values()}
+    assert {Path(a).name for a in asms} == {s + ".s" for s in B.SOURCES}, "the guard has to see every source of the library (fk_rope lives in elementwise.hip)"
+    for asm in asms:
         bad = [l for l in open(asm) if re.search(r"v_pk_(mul|fma|add)_f32.*op_sel", l)]
         assert not bad, (asm, bad[:3])

@@ -36,17 +36,24 @@ LDS_PER_GAP = int(os.environ.get("FK_GEN_LDS_PER_GAP", "2"))
 VALU_UNITS = int(os.environ.get("FK_GEN_VALU_UNITS", "9"))
 
 
-def requests(ps):
-    return [(f"s_add_u32 m0, %[ldsw], {ps * IMG}", "global_load_lds_dwordx4 %[vo0], %[kb]"),
-            (f"s_add_u32 m0, %[ldsw], {ps * IMG + 1024}", "global_load_lds_dwordx4 %[vo1], %[kb]"),
-            (f"s_add_u32 m0, %[ldsw], {(NS + ps) * IMG}", "global_load_lds_dwordx4 %[vo2], %[vb]"),
-            (f"s_add_u32 m0, %[ldsw], {(NS + ps) * IMG + 1024}", "global_load_lds_dwordx4 %[vo3], %[vb]")]
+def requests(ps, base="ldsw"):
+    return [(f"s_add_u32 m0, %[{base}], {ps * IMG}", "global_load_lds_dwordx4 %[vo0], %[kb]"),
+            (f"s_add_u32 m0, %[{base}], {ps * IMG + 1024}", "global_load_lds_dwordx4 %[vo1], %[kb]"),
+            (f"s_add_u32 m0, %[{base}], {(NS + ps) * IMG}", "global_load_lds_dwordx4 %[vo2], %[vb]"),
+            (f"s_add_u32 m0, %[{base}], {(NS + ps) * IMG + 1024}", "global_load_lds_dwordx4 %[vo3], %[vb]")]
 
 
-def gen(slot, kind):
-    """kind: 'steady', 'first' (no previous tile) or 'drain' (only the previous tile's half 1; `slot` = the slot of that tile + 1)"""
+def gen(slot, kind, generic=False):
+    """kind: 'steady', 'first' (no previous tile) or 'drain' (only the previous tile's half 1; `slot` = the slot of that tile + 1).
+    generic: ONE block for any ring slot — the caller passes the LDS addresses already moved to the slots (aq / va0 / va1: this tile's
+    slot; vp0 / vp1: the previous tile's slot; ldsn: the slot of the tile requested by this step), the immediates are those of slot 0.
+    Used for the few steps outside the unrolled steady loop (first, aligning, tail, drain), where a switch over four per-slot blocks made
+    hipcc move the carried scores and an accumulator through scratch."""
     sp = (slot + NS - 1) % NS
     koff, voff, vpoff = slot * IMG, (NS + slot) * IMG, (NS + sp) * IMG
+    vpn = "va"
+    if generic:
+        koff, voff, vpoff, vpn = 0, NS * IMG, NS * IMG, "vp"
     prev, cur = kind != "first", kind != "drain"
     mf, lds, va = [None], {}, {}
     idx = {}                                                   # group -> index of its first MFMA
@@ -91,7 +98,7 @@ def gen(slot, kind):
         for s in range(2):
             for dt in range(2):
                 for t in range(2):
-                    lds[("tp", s, dt, t)] = (f"ds_read_b64_tr_b16 {vr(VTP + 4 * (2 * s + dt) + 2 * t, 2)}, %[va{dt ^ t}] offset:{vpoff + 4096 + (16 * s + 8 * t) * 128}",
+                    lds[("tp", s, dt, t)] = (f"ds_read_b64_tr_b16 {vr(VTP + 4 * (2 * s + dt) + 2 * t, 2)}, %[{vpn}{dt ^ t}] offset:{vpoff + 4096 + (16 * s + 8 * t) * 128}",
                                              0, idx["pv1"] + 2 * s + dt)
     # ---- VALU: per half  part a = exp2 (in place), part b = row-sum tree, l, rmax, packing
     def part_a(u, rel, dl):
@@ -126,7 +133,7 @@ def gen(slot, kind):
     tail = []
     if cur:
         gaps = [2, 5, 8, 11] if prev else [2, 4, 7, 10]
-        dma_at = dict(zip(gaps, requests((slot + 2) % NS)))
+        dma_at = dict(zip(gaps, requests(0, "ldsn") if generic else requests((slot + 2) % NS)))
         if os.environ.get("FK_GEN_ABLATE_DMA"):                  # timing experiments only (wrong results)
             dma_at = {}
         # end of the step: tile i + 1 (requested one step ago) has landed, this step's requests stay in flight; the barrier publishes it and
@@ -141,7 +148,7 @@ def main():
     req_ops = '[vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [kb] "s"(kb), [vb] "s"(vb), [ldsw] "s"(ldsw)'
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen/gen_fwd_asm.py - do not edit.  Lean forward tile steps per ring slot (see the generator's header).\n")
-        for kind in ("steady", "first", "drain"):
+        for kind in ("steady",):                               # per-slot blocks: the unrolled steady loop only (first / drain / stray steps: the generic blocks below)
             for slot in range(NS):
                 ins = gen(slot, kind)
                 body = ins
@@ -150,12 +157,29 @@ def main():
                 f.write("  asm volatile(\n")
                 for i in body:
                     f.write(f'      "{i}\\n\\t"\n')
-                f.write('      : [o0] "+v"(o0), [o1] "+v"(o1), "+{v[212:227]}"(sc1), [l] "+v"(l), [rmax] "+v"(rmax)\n')
+                # the first step only WRITES the carried scores (its S'(half 1) chain starts from src_c = 0): an output-only operand, so
+                # nothing has to be initialised or kept alive in v[212:227] in front of it
+                sc1c = '"=&{v[212:227]}"(sc1)' if kind == "first" else '"+{v[212:227]}"(sc1)'
+                f.write(f'      : [o0] "+v"(o0), [o1] "+v"(o1), {sc1c}, [l] "+v"(l), [rmax] "+v"(rmax)\n')
                 f.write('      : [qf0] "v"(qf[0]), [qf1] "v"(qf[1]), [qf2] "v"(qf[2]), [qf3] "v"(qf[3]),\n')
                 f.write('        [aq0] "v"(aq[0]), [aq1] "v"(aq[1]), [aq2] "v"(aq[2]), [aq3] "v"(aq[3]), [va0] "v"(va0), [va1] "v"(va1),\n')
                 f.write(f"        {req_ops}\n")
                 f.write(f"      : {clob}, \"scc\", \"memory\");\n}}\n")
                 f.write(f"// {kind}: {len(ins)} instructions\n")
+        for kind in ("steady", "first", "drain"):
+            ins = gen(0, kind, generic=True)
+            f.write(f"FK_DEV void fwd_{kind}_asm_gen(f32x16& o0, f32x16& o1, f32x16& sc1, float& l, float& rmax, const bf16x8 (&qf)[4],\n"
+                    f"    const unsigned (&aq)[4], unsigned va0, unsigned va1, unsigned vp0, unsigned vp1, const unsigned (&vo)[4], uint64_t kb, uint64_t vb, unsigned ldsn) {{\n")
+            f.write("  asm volatile(\n")
+            for i in ins:
+                f.write(f'      "{i}\\n\\t"\n')
+            sc1c = '"=&{v[212:227]}"(sc1)' if kind == "first" else '"+{v[212:227]}"(sc1)'
+            f.write(f'      : [o0] "+v"(o0), [o1] "+v"(o1), {sc1c}, [l] "+v"(l), [rmax] "+v"(rmax)\n')
+            f.write('      : [qf0] "v"(qf[0]), [qf1] "v"(qf[1]), [qf2] "v"(qf[2]), [qf3] "v"(qf[3]),\n')
+            f.write('        [aq0] "v"(aq[0]), [aq1] "v"(aq[1]), [aq2] "v"(aq[2]), [aq3] "v"(aq[3]), [va0] "v"(va0), [va1] "v"(va1), [vp0] "v"(vp0), [vp1] "v"(vp1),\n')
+            f.write('        [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [kb] "s"(kb), [vb] "s"(vb), [ldsn] "s"(ldsn)\n')
+            f.write(f"      : {clob}, \"scc\", \"memory\");\n}}\n")
+            f.write(f"// {kind} (any slot): {len(ins)} instructions\n")
         for slot in range(NS):
             f.write(f"FK_DEV void fwd_request_asm_slot{slot}(const unsigned (&vo)[4], uint64_t kb, uint64_t vb, unsigned ldsw) {{\n  asm volatile(\n")
             for m0, ld in requests(slot):
