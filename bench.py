@@ -300,6 +300,72 @@ def parity_live(dev):
             "within_bounds": bool(rel < 1e-2 and perr < 5e-2 and cos[worst] >= 0.99)}
 
 
+def other_configs(dev, steps=10, warmup=3):
+    """The other single-GPU BASELINE.json configurations, measured live on rank 0 after the headline run (about two seconds): bf16
+    training step (fwd + bwd + clip + AdamW) on synthetic inputs, ms/step, frames/s and the fraction of the dense bf16 MFMA peak from
+    SURVEY 8d's algorithmic work per frame (cfg5: 57.7 MFLOP/frame; cfg1: 16.0 GFLOP/sample = 80 MFLOP/frame).  These are launch- and
+    traffic-bound problems (a few hundred kernels of 5-30 us per step): the fraction says how far, not a target."""
+    import frankenstein_amd as fa
+    from frankenstein_amd.utils import train_utils as tu
+    fa.set_compute_dtype("bf16")
+    tc = tu.TrainConfig(mixed_precision=True, use_scheduler=False, learning_rate=1e-4)
+    g = torch.Generator(device=dev).manual_seed(4321)
+
+    def timeit(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    out = {}
+    from frankenstein_amd.models import simple_mae as sm
+    ecfg = sm.SimpleEncoderConfig(block_size=600, patch_size=256, n_layers=6, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+    dcfg = sm.SimpleMAEConfig(n_layers=2, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+    m = sm.SimpleMAE(ecfg, dcfg).to(dev)
+    opt = tu.FusedAdamW(m, lr=1e-4, weight_decay=1e-5, grad_clip=1.0)
+    st = [0]
+    for B in (32, 256):
+        x = torch.randn(B, 600, 256, device=dev, generator=g)
+
+        def step():
+            tu.train_step(m, (x, None, None), opt, st[0], tc)
+            st[0] += 1
+        dt = timeit(step)
+        out[f"cfg5_simple_mae_b{B}"] = {"workload": f"SimpleMAE pre-training (BASELINE configs[4], SURVEY cfg5): 6+2 layers d=384, 600 frame tokens, 75 % masked, per-GPU batch {B}",
+                                        "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(B * 600 / dt, 1),
+                                        "mfma_frac": round(B * 600 / dt * 57.7e6 / MFMA_PEAK_BF16, 4)}
+    del m, opt
+    from frankenstein_amd.models import brainformer as bf
+    from frankenstein_amd.models.gpt2_model import GPT, GPTConfig
+    from frankenstein_amd.models.notebook_models import BrainEncoder, Franky
+    enc = bf.MAEConfig(window_size=200, n_electrodes=256, patch_size=25, dim=128, n_layers=2, head_dim=32, hidden_dim=512, n_heads=4, n_kv_heads=4)
+    cfg = bf.Config(encoder=enc, n_output_tokens=32, output_dim=128, dim=128, n_layers=2, head_dim=32, hidden_dim=256, n_heads=4, n_kv_heads=4)
+    fr = Franky(BrainEncoder(cfg), GPT(GPTConfig(block_size=1024, vocab_size=50257, n_layer=2, n_head=4, n_embd=128, dropout=0.0, bias=True))).to(dev)
+    opt = tu.FusedAdamW(fr, lr=1e-4, weight_decay=1e-5, grad_clip=1.0)
+    x = torch.randn(4, 200, 256, device=dev, generator=g)
+    tok = torch.randint(0, 50257, (4, 25), device=dev, generator=g)
+    tok[:, -3:] = -100
+
+    def step1():
+        tu.train_step(fr, (x, tok, None), opt, st[0], tc)
+        st[0] += 1
+    dt = timeit(step1)
+    out["cfg1_franky_b4"] = {"workload": "Franky = brain encoder + gpt2-nano (BASELINE configs[0], SURVEY cfg1), B = 4, T = 200, eager step",
+                             "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(800 / dt, 1), "mfma_frac": round(800 / dt * 80e6 / MFMA_PEAK_BF16, 5)}
+    try:
+        gstep = tu.GraphedTrainStep(fr, (x, tok, None), opt, tc)
+        dt = timeit(lambda: gstep((x, tok, None), 0))
+        out["cfg1_franky_b4"]["graphed_ms_per_step"] = round(dt * 1e3, 3)
+    except Exception as e:
+        out["cfg1_franky_b4"]["graphed_ms_per_step"] = None
+        torch.cuda.synchronize()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,6 +376,7 @@ def main():
     ap.add_argument("--head", default="l1", choices=["l1", "ce"], help="l1: the headline workload; ce: cfg2's CE-head variant (25 tokens, V = 50257)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the live timing of BASELINE configs[4] (SimpleMAE, B = 32 / 256) and configs[0] (Franky)")
     ap.add_argument("--no-parity", action="store_true", help="skip the live bf16-vs-reference check at B = 1 (tests/golden/cfg2_b1*.npz)")
     ap.add_argument("--all-timers", action="store_true", help="HIP-event timing of every kernel family (default: the roofline kernel family only)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous only, gloo on the CPU (no GPU work)")
@@ -437,6 +504,10 @@ def main():
         }
         if args.dtype == "bf16" and not args.no_parity:
             out["parity"] = parity_live(dev)
+        if world == 1 and not args.no_other_configs:
+            del model, opt, pool
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

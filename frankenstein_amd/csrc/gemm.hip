@@ -1065,13 +1065,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring192_kernel(NtArgs p) {
   }
 }
 
+// Grid of the persistent NT kernels: G workgroups per CU-sized wave (FK_NT_GRID_MULT, default 1 = one workgroup per CU, each walking its
+// static share of its XCD's tile range).  With G > 1 the ranges are G times shorter and the surplus workgroups start as CUs come free, so
+// a CU that another kernel holds (a collective's channel) costs its launch one short range instead of a whole one.
+static unsigned persistent_grid(int64_t nt) {
+  static const int g = [] { const char* e = getenv("FK_NT_GRID_MULT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+  const int64_t cap = 256LL * g;
+  return (unsigned)(nt < cap ? nt : cap);
+}
+
 template <typename TO>
 static void launch_ring192(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
   const int64_t nt = fk_cdiv(M, 256) * (N / 192);
   static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring192_kernel<TO, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, R192_LDS) == hipSuccess);
   (void)once;
-  hipLaunchKernelGGL((gemm_nt_ring192_kernel<TO, 0>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R192_LDS, s, p);
+  hipLaunchKernelGGL((gemm_nt_ring192_kernel<TO, 0>), dim3(persistent_grid(nt)), dim3(512), R192_LDS, s, p);
 }
 
 template <typename TO, int EPI>
@@ -1080,7 +1089,7 @@ static void launch_ring2_epi(const NtArgs& p, int64_t M, int64_t N, hipStream_t 
   static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring2_kernel<TO, EPI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS) == hipSuccess);
   (void)once;
-  hipLaunchKernelGGL((gemm_nt_ring2_kernel<TO, EPI>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R2_LDS, s, p);
+  hipLaunchKernelGGL((gemm_nt_ring2_kernel<TO, EPI>), dim3(persistent_grid(nt)), dim3(512), R2_LDS, s, p);
 }
 template <typename TO>
 static void launch_ring2(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {
@@ -1099,7 +1108,7 @@ static void launch_ring_epi(const NtArgs& p, int64_t M, int64_t N, hipStream_t s
   static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<TO, BN_, RB, NS, EPI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS) == hipSuccess);
   (void)once;
-  hipLaunchKernelGGL((gemm_nt_ring_kernel<TO, BN_, RB, NS, EPI>), dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), R::LDS, s, p);
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<TO, BN_, RB, NS, EPI>), dim3(persistent_grid(nt)), dim3(512), R::LDS, s, p);
 }
 template <typename TO, int BN_, int RB, int NS>
 static void launch_ring(const NtArgs& p, int64_t M, int64_t N, hipStream_t s) {   // one instantiation per fused epilogue mode
@@ -1602,7 +1611,7 @@ static int launch_nt(const char* name, const void* A, int64_t lda, const void* B
         // large projections: 256 x 256 tiles, 1 block per CU (the 256x128
                                                                 // variant measured slower than 128x128 at N = 384)
     const int64_t nt = fk_cdiv(M, 256) * (N / 256);
-    dim3 bgrid((unsigned)(nt < 256 ? nt : 256)), bblock(512);
+    dim3 bgrid(persistent_grid(nt)), bblock(512);
     const size_t bsh = 2 * (size_t)(256 + 256) * ROW_BYTES;
     if (out_dtype == FK_BF16) { static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<bf16_t, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess); (void)once;
       hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 256>), bgrid, bblock, bsh, s, p); }

@@ -698,6 +698,62 @@ def test_standalone_modules_match_oracle():
     torch.testing.assert_close(cb.cross_attn(q.cuda(), h.cuda()).cpu(), want, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_block_without_rope_takes_the_prescaled_kernels_in_bf16(masked, monkeypatch):
+    """Attention blocks WITHOUT RoPE (the MAE / SimpleMAE decoders: models/brainformer.py:462-463, models/simple_mae:372-389) at head_dim
+    64 in bf16 mode: the projection runs through the RoPE epilogue with an identity table so that the queries leave it pre-scaled and the
+    lean attention kernels serve the block.  Forward and every gradient against the fp32 oracle (bf16 bounds), and against the same
+    block on the generic kernels (FK_ATTN_NO_IDENT_PRESCALE=1) — the two paths must agree to bf16 rounding."""
+    from frankenstein_amd.models import brainformer as bf
+    cfg = bf.MAEConfig(window_size=8, n_electrodes=25, patch_size=4, dim=128, n_layers=1, head_dim=64, hidden_dim=256, n_heads=2, n_kv_heads=2)
+    T = 200                                         # ragged against every tile size
+    blk = bf.Block(cfg)
+    names = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    st = synth.make_state(names)
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    blk.cuda()
+    sd = {"b." + k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st.items()}
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, T, 128, generator=g)
+    dy = torch.randn(3, T, 128, generator=g)
+    mt = None
+    if masked:
+        valid = torch.ones(3, T, dtype=torch.bool)
+        valid[1, 150:] = False
+        valid[2, 64:] = False
+        mt = (valid[:, None, :] & valid[:, :, None])[:, None]          # SimpleMAE's padding mask (models/simple_mae:228-236)
+    xr = x.clone().requires_grad_(True)
+    want = R.block(sd, "b.", xr, cfg, None if mt is None else (mt | ~valid[:, None, :, None]), None)     # padded query rows: any finite output, excluded below
+    rows = torch.ones(3, T, dtype=torch.bool) if mt is None else valid
+    (want * dy * rows[..., None]).sum().backward()
+
+    def run():
+        from frankenstein_amd.kernels import Mask
+        blk.zero_grad(set_to_none=True)
+        xd = x.cuda().requires_grad_(True)
+        m = None if mt is None else Mask.from_padding(valid.cuda(), valid.cuda())
+        out = blk(xd, attn_mask=m, rope=None)
+        (out.float() * (dy * rows[..., None]).cuda()).sum().backward()
+        return out.float().cpu().detach(), xd.grad.float().cpu(), {k: v.grad.float().cpu().clone() for k, v in blk.named_parameters()}
+
+    fa.set_compute_dtype("bf16")
+    try:
+        o1, dx1, g1 = run()
+        monkeypatch.setenv("FK_ATTN_NO_IDENT_PRESCALE", "1")
+        o2, dx2, g2 = run()
+    finally:
+        fa.set_compute_dtype("fp32")
+    sel = rows[..., None].expand_as(o1)
+    for got in (o1, o2):
+        assert float((got - want.detach())[sel].abs().max()) < 6e-2
+    assert float((o1 - o2)[sel].abs().max()) < 4e-2
+    cos = lambda a, b: float((a.flatten().double() @ b.flatten().double()) / (a.norm().double() * b.norm().double() + 1e-30))
+    assert cos(dx1[rows], xr.grad[rows]) > 0.995 and cos(dx2[rows], xr.grad[rows]) > 0.995
+    for k in g1:
+        assert cos(g1[k], sd["b." + k].grad) > 0.99, (k, cos(g1[k], sd["b." + k].grad))
+        assert cos(g1[k], g2[k]) > 0.995, k
+
+
 def test_run_train_model_end_to_end(tmp_path):
     """The reference's driver contract (utils/train_utils.py:93-185): loaders -> steps -> eval on an interval ->
     best-val safetensors checkpoint that loads back into a fresh model (same state-dict keys)."""

@@ -31,7 +31,7 @@ for d in disp.values():
     p["launches"] += 1; p["ns"] += d["ns"]; p["busy"] += busy; p["gui"] += gui; p["mops"] += mops
     tot["ns"] += d["ns"]; tot["busy"] += busy; tot["gui"] += gui; tot["mops"] += mops
 doc = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU "
-                 "--kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-timers; MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / "
+                 "--kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-timers --no-parity --no-other-configs; MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / "
                  "(max(GRBM_GUI_ACTIVE) * 1024 SIMDs) per dispatch (the gfx94x derived-counter formula); MFMA TF/s = "
                  "SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 / duration  (tools/pmc_mfma_util.py)",
        "whole_trace": {"mfma_util_pct": 100 * tot["busy"] / (tot["gui"] * 1024), "mfma_tflops": tot["mops"] * 512 / tot["ns"] / 1e3,

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${1:-r02}
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-timers"
+B="python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-timers --no-parity --no-other-configs"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d ${OUT}_f -- $B > ${OUT}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d ${OUT}_w -- $B > ${OUT}_pmc_w.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU -d ${OUT}_m -- $B > ${OUT}_pmc_m.log 2>&1

@@ -37,7 +37,7 @@ if len(bwd) != 2:
 if not bwd:
     bwd = [k for k in res if "attn_bwd_dkdv" in k and "DF16bLi64" in k] + [k for k in res if "attn_bwd_dq" in k and "DF16bLi64" in k]
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 1 "
-                 "--warmup 1 --no-cpu-baseline --no-timers`; bytes = FETCH_SIZE*1024*2 (gfx950 wide-stream correction, "
+                 "--warmup 1 --no-cpu-baseline --no-timers --no-parity --no-other-configs`; bytes = FETCH_SIZE*1024*2 (gfx950 wide-stream correction, "
                  "MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024; mean over the encoder-sized launches of each kernel",
        "fk_attn_bwd_bytes_per_call": int(sum(res[k]["read_bytes"] + res[k]["write_bytes"] for k in bwd)),
        "kernels": res}
