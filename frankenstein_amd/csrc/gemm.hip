@@ -1065,11 +1065,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring192_kernel(NtArgs p) {
   }
 }
 
-// Grid of the persistent NT kernels: G workgroups per CU-sized wave (FK_NT_GRID_MULT, default 1 = one workgroup per CU, each walking its
-// static share of its XCD's tile range).  With G > 1 the ranges are G times shorter and the surplus workgroups start as CUs come free, so
-// a CU that another kernel holds (a collective's channel) costs its launch one short range instead of a whole one.
+// Grid of the persistent NT kernels: G workgroups per CU-sized wave (FK_NT_GRID_MULT, default 4), each walking its static share of its
+// XCD's tile range; the surplus workgroups start as CUs come free.  With one workgroup per CU (G = 1) a CU that another kernel holds —
+// a collective's channel beside the backward — makes its workgroup start late and the launch end a whole range late: beside an occupant
+// of 8 workgroups x 48 KiB of LDS the cfg2 launches took x1.33 ... x1.66 their quiet time; with G = 4 x0.91 ... x1.06, at the same quiet
+// time and the same step time (tools/occupant_probe.py, profiles/r04_g_occupant_probe.txt, r04_g_grid_mult_step.txt).
 static unsigned persistent_grid(int64_t nt) {
-  static const int g = [] { const char* e = getenv("FK_NT_GRID_MULT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+  static const int g = [] { const char* e = getenv("FK_NT_GRID_MULT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   const int64_t cap = 256LL * g;
   return (unsigned)(nt < cap ? nt : cap);
 }
@@ -1537,7 +1539,11 @@ int tn_big_tb(int64_t N1, int64_t N2) {
 }
 int tn_big_splits(int64_t M, int64_t N1, int64_t N2) {
   const int64_t tiles = (N1 / TG_A) * (N2 / tn_big_tb(N1, N2));
-  int64_t want = 256 / tiles;                               // one wave of blocks, one block per CU
+  // one wave of blocks, one block per CU; FK_TN_SPLIT_MULT = m (default 1) cuts the contraction m times finer: m waves of shorter units,
+  // so that a CU another kernel holds (a collective's channel) costs the launch 1/m of a unit, at the price of m times the slab traffic
+  // (bench.py's launcher sets 2 for data-parallel runs; tools/occupant_probe.py measures both sides)
+  static const int mult = [] { const char* e = getenv("FK_TN_SPLIT_MULT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  int64_t want = 256 / tiles * mult;
   const int64_t maxs = M / 512;                             // >= 512 rows (16 k-stages) per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
