@@ -105,7 +105,11 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
         int tt = mb % p.rope_T;
         const float* tp = rope_table + (nb < p.rope_qcols ? p.rope_qoff : (int64_t)0) + (int64_t)(mb / p.rope_T) * p.rope_bs + ((int64_t)(p.rope_off + tt) * (p.rope_D / 2) + (nb % p.rope_D) / 2) * 2;
         auto fetch = [&](int ps, f32x4& lo, f32x4& hi) {
+#ifdef FK_PROBE_NO_ROPE_TABLE      // timing builds only (wrong results): what the (cos, sin) loads of the fused RoPE cost
+          if (mb + 8 * ps < p.M) { lo = f32x4{1.0f, 0.0f, 1.0f, 0.0f}; hi = lo; }
+#else
           if (mb + 8 * ps < p.M) { lo = *reinterpret_cast<const f32x4*>(tp); hi = *reinterpret_cast<const f32x4*>(tp + 4); }
+#endif
           tt += 8;
           tp += 8 * p.rope_D;
           while (tt >= p.rope_T) { tt -= p.rope_T; tp += p.rope_bs - (int64_t)p.rope_T * p.rope_D; }

@@ -133,6 +133,17 @@ def simple_mae_small():
     return ecfg, mcfg
 
 
+def cfg5_simple_mae(pad_from=(600, 590, 333, 599)):
+    """BASELINE configs[4] at SURVEY 8d's size (cfg5): SimpleMAE, 6-layer d = 384 encoder on 600 frame tokens, 2-layer decoder; the input
+    of tests/golden/cfg5_simple_mae.npz: B = 4 synthetic samples, three of them with zero-padded tails."""
+    ecfg = R.simple_encoder_config(block_size=600, patch_size=256, n_layers=6, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+    mcfg = R.simple_mae_config(n_layers=2, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+    x = t(synth.make_inputs(len(pad_from), 600, 256)).clone()
+    for b, p0 in enumerate(pad_from):
+        x[b, int(p0):] = 0.0
+    return ecfg, mcfg, x
+
+
 def train_accum(n_items: int = 10):
     """Dataset of the grad_accum fixture (tests/golden/train_accum.npz): sample i -> (x_i, y_i)."""
     cfg, _, _ = bf_l1_small()

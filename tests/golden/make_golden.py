@@ -530,8 +530,45 @@ def cfg2_b8_grad_golden(B=8, MB=2):
                        f"= gradient of the B = {B} mean L1 loss; CPU fp32"))
 
 
+def cfg5_simple_mae_golden(B=4):
+    """BASELINE configs[4] AT THE SIZE SURVEY 8d names — SimpleMAE: 6-layer d = 384 encoder on 600 frame tokens (patch 256), 2-layer decoder,
+    masking ratio 0.75 — through the reference (models/simple_mae + the notebook's config dataclasses), B = 4 with zero-padded tails of three
+    samples: loss, the reconstruction at the masked frames, the binary mask, gradient summaries and 256 evenly spaced samples of every
+    gradient.  The random index sets are fixture INPUTS (torch's CPU generator is not reproducible on the device)."""
+    import contextlib
+    import dataclasses
+    import io
+    from tests import cases as TC
+    import_reference()                                   # the harness stubs for simple_parsing / wandb
+    sm = importlib.machinery.SourceFileLoader("ref_simple_mae", str(REF / "models" / "simple_mae")).load_module()
+    ns3 = dict(dataclass=dataclasses.dataclass, Serializable=object)
+    exec("".join(json.load(open(REF / "notebooks" / "simple_mae.ipynb"))["cells"][1]["source"]), ns3)
+    ecfg = ns3["SimpleEncoderConfig"](block_size=600, patch_size=256, n_layers=6, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+    mcfg = ns3["SimpleMAEConfig"](n_layers=2, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = sm.SimpleMAE(ecfg, mcfg).float()
+    load_synth(m, skip=())
+    x = torch.from_numpy(synth.make_inputs(B, 600, 256))
+    x[1, 590:] = 0.0
+    x[2, 333:] = 0.0
+    x[3, 599:] = 0.0
+    torch.manual_seed(4321)
+    masked, unmasked = m.get_masking_indices(0.75, x)
+    torch.manual_seed(4321)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss, recon, bmask = m(x, masking_ratio=0.75, return_preds=True)
+    loss.backward()
+    gn, gr = summarize(grads_of(m))
+    sn, sr = TC.sample_rows(grads_of(m))
+    save("cfg5_simple_mae", loss=np.array(float(loss.detach())), masked=masked.numpy(), unmasked=unmasked.numpy(), pad_from=np.array([600, 590, 333, 599]),
+         recon_every4=recon.detach().numpy().astype(np.float32)[:, ::4], recon_sum=np.array(float(recon.detach().double().sum())),
+         binary_mask=bmask.detach().numpy(), grad_names=gn, grad_rows=gr, grad_samples=sr)
+
+
 if __name__ == "__main__":
-    if os.environ.get("FK_GOLDEN_ONLY") == "cfg2_b3":
+    if os.environ.get("FK_GOLDEN_ONLY") == "cfg5_simple_mae":
+        cfg5_simple_mae_golden()
+    elif os.environ.get("FK_GOLDEN_ONLY") == "cfg2_b3":
         cfg2_batch_golden()
     elif os.environ.get("FK_GOLDEN_ONLY") == "cfg2_b32_fwd":
         cfg2_b32_fwd_golden()
@@ -551,3 +588,4 @@ if __name__ == "__main__":
         cfg2_batch_golden()
         cfg2_b8_grad_golden()
         cfg2_b32_fwd_golden()
+        cfg5_simple_mae_golden()

@@ -839,6 +839,40 @@ def test_simple_mae_small_fp32(golden):
     assert torch.isfinite(l2)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_cfg5_simple_mae_full_size_vs_reference(golden, mode):
+    """BASELINE configs[4] AT ITS SIZE (6-layer d = 384 encoder on 600 frame tokens, 2-layer decoder, 75 % masked) against the
+    reference's own run (tests/golden/cfg5_simple_mae.npz: B = 4, zero-padded tails, the index sets recorded as inputs): fp32 mode — loss,
+    reconstruction, binary mask, gradient rows; bf16 mode (pre-scaled kernels in encoder AND decoder) — loss 1e-2 relative, reconstruction
+    8e-2, per-parameter gradient cosine >= 0.99."""
+    from frankenstein_amd.models import simple_mae as sm
+    z = golden("cfg5_simple_mae")
+    oe, om, x = C.cfg5_simple_mae(tuple(int(v) for v in z["pad_from"]))
+    ecfg = sm.SimpleEncoderConfig(block_size=600, patch_size=256, n_layers=6, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+    mcfg = sm.SimpleMAEConfig(n_layers=2, dim=384, hidden_dim=1536, head_dim=64, n_heads=6, n_kv_heads=6)
+    fa.set_compute_dtype(mode)
+    try:
+        m = sm.SimpleMAE(ecfg, mcfg)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dict(R.simple_mae_shapes(oe, om))
+        m = load_synth(m, skip=())
+        idx = (torch.from_numpy(z["masked"]).cuda(), torch.from_numpy(z["unmasked"]).cuda())
+        loss, recon, bmask = m(x.cuda(), masking_ratio=0.75, return_preds=True, indices=idx)
+        loss.backward()
+        rerr = float(np.abs(recon.float().cpu().numpy()[:, ::4] - z["recon_every4"]).max())
+        np.testing.assert_array_equal(bmask.cpu().numpy(), z["binary_mask"])
+        if mode == "fp32":
+            assert abs(float(loss) - float(z["loss"])) < 2e-5 and rerr < 5e-4, (float(loss), rerr)
+            check_grad_rows(m, z, rtol=5e-3, atol=5e-4)
+        else:
+            rel = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+            cos = _cosines(m, z)
+            worst = min(cos, key=cos.get)
+            assert rel < 1e-2 and rerr < 8e-2, (rel, rerr)
+            assert cos[worst] >= 0.99, (worst, cos[worst])
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
 def test_input_pipeline_matches_reference(golden):
     """block-wise z-score (std == 0 -> 1) + Gaussian smoothing + pad / truncate on device vs
     utils/data_utils.py process_signal / pad_truncate_brain_list / z_score_per_block_scaling run on the reference (float64)."""

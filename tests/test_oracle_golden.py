@@ -248,6 +248,25 @@ def test_simple_mae_small(golden):
     check_grads(grads(loss, sd), z)
 
 
+def test_cfg5_simple_mae_full_size(golden):
+    """BASELINE configs[4] at the size SURVEY 8d names (6-layer d = 384 encoder on 600 frame tokens, 2-layer decoder, 75 % masked) run
+    through the reference (tests/golden/cfg5_simple_mae.npz, B = 4, three padded tails): the oracle reproduces loss, reconstruction and
+    gradient summaries."""
+    z = golden("cfg5_simple_mae")
+    ecfg, mcfg, x = C.cfg5_simple_mae(tuple(int(v) for v in z["pad_from"]))
+    sd = leafify(C.state(R.simple_mae_shapes(ecfg, mcfg)))
+    masked, unmasked = torch.from_numpy(z["masked"]), torch.from_numpy(z["unmasked"])
+    loss, pred = R.simple_mae_forward(sd, x, ecfg, mcfg, masked, unmasked)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    br = torch.arange(x.shape[0])[:, None]
+    rec = torch.zeros_like(x).index_put((br, masked), pred.detach()).index_put((br, unmasked), x[br, unmasked])
+    np.testing.assert_allclose(rec[:, ::4].numpy(), z["recon_every4"], atol=1e-4)
+    names, rows = C.summarize_rows(grads(loss, sd))
+    want = {str(n): r for n, r in zip(z["grad_names"], z["grad_rows"])}
+    for n, r in zip(names, rows):
+        np.testing.assert_allclose(r, want[n], rtol=2e-3, atol=2e-5, err_msg=n)
+
+
 def test_train_loop_grad_accum_matches_reference_run(golden):
     """The reference's run_train_model under accelerate with grad_accum = 2 (golden produced by running that loop itself): the
     oracle's restatement — update on sync micro-steps only, from that micro-batch's gradient / grad_accum — reproduces the loss of
