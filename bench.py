@@ -513,7 +513,7 @@ def main():
             "kernel_families": detail,
             "loss": round(float(loss), 5),
         }
-        if args.dtype == "bf16" and not args.no_parity:
+        if world == 1 and args.dtype == "bf16" and not args.no_parity:      # N = 1 only, like cpu_baseline: the other ranks of a DP run do not wait for it
             out["parity"] = parity_live(dev)
         if world == 1 and not args.no_other_configs:
             del model, opt, pool

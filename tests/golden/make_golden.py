@@ -386,6 +386,36 @@ def vq_golden():
          **{"grad/decoder." + k: v.numpy() for k, v in grads_of(net.decoder).items()})
 
 
+def vq_cfg4_golden():
+    """The same convolution stack AT THE SIZE BASELINE configs[3] / SURVEY cfg4 names: SoundStream(C = 256, D = 64, codebook 1024, 256
+    electrodes) on [2, 600, 256] (one padded tail) — codes [2, 150, 64], reconstruction, masked L1 loss, gradient summaries + samples.  The
+    third-party VQ layer (absent, unpinned) is bypassed as in vq_conv_small: decoder(encoder(x))."""
+    for name, attrs in (("vector_quantize_pytorch", ("ResidualVQ", "VectorQuantize")), ("pytorch_model_summary", ("summary",))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            for a in attrs:
+                setattr(m, a, type(a, (torch.nn.Module,), {"__init__": lambda self, *aa, **kw: torch.nn.Module.__init__(self)}))
+            sys.modules[name] = m
+    from tests import cases as TC
+    vq = importlib.machinery.SourceFileLoader("ref_vq_brain", str(REF / "models" / "vq_brain.py")).load_module()
+    torch.manual_seed(0)
+    net = vq.SoundStream(C=256, D=64, codebook_size=1024, n_electrodes=256)
+    load_synth(net.encoder)
+    load_synth(net.decoder)
+    x = torch.from_numpy(synth.make_inputs(2, 600, 256))
+    x[1, 541:] = 0.0
+    e = net.encoder(x)
+    o = net.decoder(e)
+    loss = net.custom_l1_loss(o, x)
+    loss.backward()
+    g = {**{"encoder." + k: v for k, v in grads_of(net.encoder).items()}, **{"decoder." + k: v for k, v in grads_of(net.decoder).items()}}
+    gn, gr = summarize(g)
+    sn, sr = TC.sample_rows(g)
+    save("vq_conv_cfg4", e=e.detach().numpy(), o_every4=o.detach().numpy()[:, ::4], o_sum=np.array(float(o.detach().double().sum())),
+         loss=np.array(float(loss)), grad_names=gn, grad_rows=gr, grad_samples=sr)
+
+
 def accum_golden():
     """The reference's REAL hot loop — utils/train_utils.py:93-185 run_train_model under accelerate, CPU, fp32 — with
     grad_accum = 2 on the small L1 BrainFormer: pins what gradient accumulation means in the reference (accelerate's
@@ -578,6 +608,8 @@ if __name__ == "__main__":
         pipeline_golden()
     elif os.environ.get("FK_GOLDEN_ONLY") == "vq_conv_small":
         vq_golden()
+    elif os.environ.get("FK_GOLDEN_ONLY") == "vq_conv_cfg4":
+        vq_cfg4_golden()
     elif os.environ.get("FK_GOLDEN_ONLY") == "train_accum":
         accum_golden()
     else:
@@ -589,3 +621,4 @@ if __name__ == "__main__":
         cfg2_b8_grad_golden()
         cfg2_b32_fwd_golden()
         cfg5_simple_mae_golden()
+        vq_cfg4_golden()

@@ -919,6 +919,49 @@ def test_vq_conv_stack_matches_reference(golden):
     assert abs(float(perp) - float(z["perp"])) < 1e-3
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_vq_conv_stack_at_baseline_size_vs_reference(golden, mode):
+    """BASELINE configs[3]'s front end AT ITS SIZE (SURVEY cfg4: SoundStream(C = 256, D = 64, codebook 1024, 256 electrodes), [2, 600, 256] with
+    a padded tail) against the reference's convolution stack on the CPU (tests/golden/vq_conv_cfg4.npz; the third-party VQ layer bypassed
+    on both sides — its arithmetic stays parity-unpinned): codes, reconstruction, masked L1 loss, gradients."""
+    from frankenstein_amd.models import vq_brain as vq
+    z = golden("vq_conv_cfg4")
+    fa.set_compute_dtype(mode)
+    try:
+        net = vq.SoundStream(C=256, D=64, codebook_size=1024, n_electrodes=256)
+        load_synth(net.encoder)
+        load_synth(net.decoder)
+        net.cuda()
+        x = torch.from_numpy(synth.make_inputs(2, 600, 256)).clone()
+        x[1, 541:] = 0.0
+        x = x.cuda()
+        e = net.encoder(x)
+        o = net.decoder(e)
+        loss = net.custom_l1_loss(o, x)
+        loss.backward()
+        eerr = float(np.abs(e.float().cpu().detach().numpy() - z["e"]).max())
+        oerr = float(np.abs(o.float().cpu().detach().numpy()[:, ::4] - z["o_every4"]).max())
+        g = {k: v for k, v in named_grads(net).items() if not k.startswith("quantizer")}
+        names, rows = C.sample_rows(g)
+        want = {str(n): r for n, r in zip(z["grad_names"], z["grad_samples"])}
+        assert set(names) == set(want)
+        cos = {}
+        for n, r in zip(names, rows):
+            den = float(np.linalg.norm(r) * np.linalg.norm(want[n]))
+            cos[n] = float(np.dot(r, want[n]) / den) if den > 0 else 1.0
+        worst = min(cos, key=cos.get)
+        scale = float(np.abs(z["e"]).max())
+        if mode == "fp32":
+            assert abs(float(loss) - float(z["loss"])) < 2e-5 and eerr < 1e-3 * max(1.0, scale) and oerr < 1e-3 * max(1.0, scale), (float(loss), eerr, oerr, scale)
+            for n, r in zip(names, rows):
+                np.testing.assert_allclose(r, want[n], rtol=5e-3, atol=5e-5 * max(1.0, float(np.abs(want[n]).max())), err_msg=n)
+        else:
+            rel = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+            assert rel < 2e-2 and eerr < 5e-2 * max(1.0, scale) and cos[worst] >= 0.98, (rel, eerr, scale, worst, cos[worst])
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
 def test_soundstream_trains():
     """End-to-end SoundStream step with the build-defined VQ (cosine lookup, straight-through, commitment loss, EMA codebook):
     finite loss, gradients reach the encoder through the quantiser, the lookup returns the most similar unit-norm code, and a few
