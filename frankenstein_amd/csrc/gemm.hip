@@ -44,6 +44,13 @@ struct NtArgs {
 #ifndef FK_NT_STORES_GEMM
 #define FK_NT_STORES_GEMM 1      // 0: plain stores; 1 (default, -0.4 ms per cfg2 step): all fused-epilogue outputs non-temporal; 2: only the large ones (SwiGLU forward / backward, QKV + RoPE)
 #endif
+#ifndef FK_NT_LOADS_GEMM
+#define FK_NT_LOADS_GEMM 0       // 1: the saved h13 rows of the SwiGLU backward (read once) loaded non-temporal; 2: the residual rows too
+#endif
+template <int LEVEL, typename V> FK_DEV V ld_once(const V* q) {
+  if constexpr (FK_NT_LOADS_GEMM >= LEVEL) return __builtin_nontemporal_load(q);
+  else return *q;
+}
 template <int EPI, typename V> FK_DEV void st_out(V* q, const V& v) {
   fk_st<(FK_NT_STORES_GEMM == 1) || (FK_NT_STORES_GEMM == 2 && EPI >= 1)>(q, v);
 }
@@ -89,7 +96,7 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
         int rr = p.res_rows > 0 ? mb % (int)p.res_rows : mb;
         auto fetch = [&](int ps) {
           bf16x8 r = {};
-          if (mb + 8 * ps < p.M && col_ok) r = *reinterpret_cast<const bf16x8*>(res + (int64_t)rr * p.ldr + nb);
+          if (mb + 8 * ps < p.M && col_ok) r = ld_once<2>(reinterpret_cast<const bf16x8*>(res + (int64_t)rr * p.ldr + nb));
           rr += 8;
           if (p.res_rows > 0) { while (rr >= (int)p.res_rows) rr -= (int)p.res_rows; }
           return r;
@@ -129,8 +136,8 @@ FK_DEV void nt_epilogue(const NtArgs& p, f32x16 (&acc)[NI][2], char* stg, int mr
         hq1[ps] = bf16x8{};
         if (mb + 8 * ps < p.M && col_ok) {
           const T* hp = (const T*)p.aux + (int64_t)(mb + 8 * ps) * p.ldaux + 2 * nb;
-          hq0[ps] = *reinterpret_cast<const bf16x8*>(hp);
-          hq1[ps] = *reinterpret_cast<const bf16x8*>(hp + 8);
+          hq0[ps] = ld_once<1>(reinterpret_cast<const bf16x8*>(hp));
+          hq1[ps] = ld_once<1>(reinterpret_cast<const bf16x8*>(hp + 8));
         }
       }
     }
