@@ -513,12 +513,21 @@ def main():
             "kernel_families": detail,
             "loss": round(float(loss), 5),
         }
+        # the side legs never cost the headline line: a failure is reported in its block
         if world == 1 and args.dtype == "bf16" and not args.no_parity:      # N = 1 only, like cpu_baseline: the other ranks of a DP run do not wait for it
-            out["parity"] = parity_live(dev)
+            try:
+                out["parity"] = parity_live(dev)
+            except Exception as e:
+                out["parity"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and not args.no_other_configs:
             del model, opt, pool
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(dev)
+            try:
+                out["other_configs"] = other_configs(dev)
+            except Exception as e:
+                out["other_configs"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            import frankenstein_amd as fa
+            fa.set_compute_dtype(args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
