@@ -529,7 +529,10 @@ def main():
             import frankenstein_amd as fa
             fa.set_compute_dtype(args.dtype)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
