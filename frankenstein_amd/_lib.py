@@ -28,6 +28,7 @@ SIGNATURES = {
     "fk_gemm_nt_rope": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_nt_swiglu": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_nt_dswiglu": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
+    "fk_mlp_bwd_fused": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "fk_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "fk_gemm_tn": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _int, _p, _sz, _p]),
     "fk_colsum_workspace_bytes": (_sz, [_i64, _i64]),

@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libfranken_hip.so"
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_optim.hip", "pipeline.hip", "conv.hip", "decode.hip", "head_ce.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss_optim.hip", "pipeline.hip", "conv.hip", "decode.hip", "head_ce.hip", "mlp_fused.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950 has a unified file), which removes the
 # v_accvgpr_read/write traffic between the matrix results and the softmax / epilogue VALU code.
@@ -22,6 +22,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # slower (51.7 ms/step either way).  Hand-written f32x2 arithmetic (no half-swaps) is unaffected and stays.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-fno-slp-vectorize",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
+
+
+def flags_for(src: str):
+    """mlp_fused.hip keeps its 208 accumulator registers in the AGPR half (one wave per SIMD, 96 + 192 + 16 stationary registers per lane):
+    it is compiled WITHOUT -amdgpu-mfma-vgpr-form; everything else with the common flags."""
+    if src == "mlp_fused.hip":
+        return [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")]
+    return FLAGS
 
 
 def _stale(out: Path, deps) -> bool:
@@ -43,7 +51,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def cc(job):
         src, o = job
-        cmd = [HIPCC, *FLAGS, "-c", str(CSRC / src), "-o", str(o)]
+        cmd = [HIPCC, *flags_for(src), "-c", str(CSRC / src), "-o", str(o)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,0 +1,293 @@
+// mlp_fused.hip — the SwiGLU MLP's data-gradient chain as ONE attention-shaped kernel (gfx950 only).
+//
+//   reference call sites: models/brainformer.py:119-124 (MLP.forward: w2(silu(w1 x) * w3 x)), autograd of it.
+//   replaces, in the backward of the fused SwiGLU path (engine.MlpBranch.backward):
+//       dh13 = fk_gemm_nt_dswiglu(dy, W2T, h13)        (dg = dy W2T^T never stored; dh13 written: 1.2 GB per cfg2 layer)
+//       dx   = fk_gemm_nt(dh13, W13T)                  (dh13 read back: 1.2 GB)
+//   by one launch that keeps dh13 in registers between the two products (it is still written once: the weight gradients need it).
+//
+// The token is on the LANE, as the query is in the attention kernels: with C^T = A B (A: weight rows from LDS, B: activations from
+// registers) an accumulator tile holds 32 output features x 32 tokens, lane = token.  Per workgroup of 4 waves = 128 tokens
+// (one wave per SIMD; dx^T accumulators 12 tiles = 192 registers in the accumulator half, dy^T fragments 96 registers stationary) and
+// per CHUNK of 32 hidden units (64 interleaved h1 | h3 columns):
+//     dg^T [32 x 32]  = W2T_c [32 x 384] dy^T                      24 MFMAs        (W2T_c: six 32-row k-tile images in LDS)
+//     dh1, dh3        = SwiGLU derivative against the saved h13 rows (one 16-byte load per lane and k16-step), rounded to bf16:
+//                       the 8 values of a lane and step ARE the B fragment of the next product and the 16-byte dh13 store
+//     dx^T [384 x 32] += W13T_c [384 x 64] dh13^T                  48 MFMAs        (W13T_c: one 384-row image in LDS)
+// The weight chunks (72 KB) arrive by LDS-DMA into a two-slot ring, chunk c + 1 requested when chunk c starts.  Products, operand
+// slots and summation order are those of the two GEMM kernels this replaces (k in ascending 16-blocks), so dh13 and dx come out
+// bit-identical to them (tests/test_kernels_gpu.py).
+//
+// Built WITHOUT -amdgpu-mfma-vgpr-form (frankenstein_amd/build.py): the 208 accumulator registers live in the AGPR half, which is what
+// lets a wave keep 96 + 192 + 16 stationary registers at one wave per SIMD.
+#include "fk_common.h"
+
+namespace {
+
+#include "gemm_tile.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+struct MlpBwdArgs {
+  const bf16_t* dy; const bf16_t* w2t; const bf16_t* h13; const bf16_t* w13t;
+  bf16_t* dh13; bf16_t* dx;
+  int64_t lddy, ldw2t, ldh, ldw13t, lddh, lddx;
+  int M, H;
+};
+
+constexpr int MF_D = 384, MF_NW = 4, MF_TOK = MF_NW * 32;
+constexpr int MF_KT = MF_D / 64;                          // k-tile images of a W2T chunk (6)
+constexpr int MF_W2 = MF_KT * 32 * ROW_BYTES;            // 24 KiB
+constexpr int MF_W13 = MF_D * ROW_BYTES;                 // 48 KiB
+constexpr int MF_SLOT = MF_W2 + MF_W13;                  // 72 KiB
+constexpr int MF_HREG = 32 * ROW_BYTES;                  // per wave: the 32 x 128-byte h13 / dh13 tile of a chunk (4 KiB)
+constexpr int MF_LDS = 2 * MF_SLOT + MF_NW * MF_HREG;    // 160 KiB: the whole LDS of a CU
+constexpr int MF_PIECES = MF_SLOT / 1024 / MF_NW;        // LDS-DMA wave instructions per wave and chunk (18)
+constexpr int MF_ROWP = MF_D * 2 + 16;                   // padded bf16 row of the dx staging (784 B: 16-byte aligned, bank step 4)
+static_assert(MF_LDS <= 160 * 1024 && MF_TOK * MF_ROWP <= MF_LDS, "LDS of a CU");
+static_assert(MF_SLOT % (1024 * MF_NW) == 0, "whole pieces per wave");
+
+template <bool FAST_SIGMOID> FK_DEV float mf_sigmoid(float x) {
+  if constexpr (FAST_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));      // the bf16 mode's form in gemm.hip (sigmoid_f<bf16_t>)
+  else return 1.0f / (1.0f + __expf(-x));
+}
+
+// One LDS-DMA request of 1 KiB (64 lanes x 16 B): wave-uniform 64-bit base + per-lane 32-bit byte offset -> LDS address `dst` (wave-uniform,
+// through M0).  Issued as asm: the scalar-base form costs no address arithmetic per request (hipcc's builtin takes a per-lane 64-bit pointer:
+// two or three VALU instructions per request on a wave that has no partner to hide them), and hipcc's wait-count pass does not see it
+// (the waits are counted by hand below).  M0 is written one instruction ahead of its use.
+FK_DEV void mf_dma(const void* base, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
+}
+
+__global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using T = bf16_t;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = blockIdx.x * MF_TOK + wave * 32 + li;
+  const bool m_ok = m < p.M;
+  const int mc = m_ok ? m : p.M - 1;                      // rows past the end: clamped loads, no stores
+  const int nchunks = p.H / 32;
+
+  // ---- LDS-DMA of one weight chunk: pieces of 8 image rows x 128 B (1 KiB per wave instruction); every wave moves six pieces of the W2T
+  //      part (k-tile images s6 = 0..5 of 32 rows each) and twelve of the 384-row W13T image; XOR swizzle on the SOURCE column.  The
+  //      per-lane byte offsets inside a chunk are constants: chunk c starts at w2t + c * 32 rows / w13t + c * 64 columns (wave-uniform)
+  const int row8 = lane >> 3, ch = lane & 7;
+  unsigned off2[MF_W2 / 1024 / MF_NW], off13[MF_W13 / 1024 / MF_NW];
+#pragma unroll
+  for (int j = 0; j < MF_W2 / 1024 / MF_NW; ++j) {
+    const int q = wave * (MF_W2 / 1024 / MF_NW) + j, s6 = q >> 2, r = (q & 3) * 8 + row8;
+    off2[j] = (unsigned)((r * (int)p.ldw2t + s6 * 64 + ((ch ^ ((r >> 1) & 7)) << 3)) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < MF_W13 / 1024 / MF_NW; ++j) {
+    const int r = (wave * (MF_W13 / 1024 / MF_NW) + j) * 8 + row8;
+    off13[j] = (unsigned)((r * (int)p.ldw13t + ((ch ^ ((r >> 1) & 7)) << 3)) * 2);
+  }
+  // LDS: W2T ring (two 24-KiB slots), W13T ring (two 48-KiB slots), the waves' h13 tiles
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  auto w2slot = [&](int i) -> char* { return smem + i * MF_W2; };
+  auto w13slot = [&](int i) -> char* { return smem + 2 * MF_W2 + i * MF_W13; };
+  auto issue_w2 = [&](int c, int slot) __attribute__((always_inline)) {
+    const void* g2 = p.w2t + (int64_t)c * 32 * p.ldw2t;
+    const unsigned d0 = __builtin_amdgcn_readfirstlane(lds0 + slot * MF_W2 + wave * (MF_W2 / MF_NW));
+#pragma unroll
+    for (int j = 0; j < MF_W2 / 1024 / MF_NW; ++j) mf_dma(g2, off2[j], d0 + j * 1024);
+  };
+  auto issue_w13 = [&](int c, int slot) __attribute__((always_inline)) {
+    const void* g13 = p.w13t + (int64_t)c * 64;
+    const unsigned d0 = __builtin_amdgcn_readfirstlane(lds0 + 2 * MF_W2 + slot * MF_W13 + wave * (MF_W13 / MF_NW));
+#pragma unroll
+    for (int j = 0; j < MF_W13 / 1024 / MF_NW; ++j) mf_dma(g13, off13[j], d0 + j * 1024);
+  };
+  // ---- the wave's h13 rows of a chunk (32 tokens x 64 interleaved columns = 4 KiB) also arrive by LDS-DMA, into a wave-private tile
+  //      with the image's swizzle; the lane reads its four 16-byte pieces from there, the dh13 pieces go back into the SAME places and
+  //      leave as whole 128-byte row segments (eight lanes per row): per-lane row accesses (16-byte pieces of 64 different rows per
+  //      instruction) cost this kernel 190 us in loads and 530 us in stores per cfg2 call
+  char* hreg = smem + 2 * MF_SLOT + wave * MF_HREG;       // behind both weight rings
+  const int m0w = blockIdx.x * MF_TOK + wave * 32;
+  const bool wave_full = m0w + 32 <= p.M;
+  unsigned hoff[4];
+  T* hdst[4];
+  bool hrow_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = j * 8 + row8, mr = m0w + r;
+    hrow_ok[j] = mr < p.M;
+    hoff[j] = (unsigned)(((int64_t)(hrow_ok[j] ? mr : p.M - 1) * p.ldh + ((ch ^ ((r >> 1) & 7)) << 3)) * 2);      // DMA source: swizzled column piece (the launcher checks 32 bits)
+    hdst[j] = p.dh13 + (int64_t)(hrow_ok[j] ? mr : p.M - 1) * p.lddh + (ch << 3);                                 // store: logical piece ch of row r
+  }
+  const unsigned hreg_lds = __builtin_amdgcn_readfirstlane(lds0 + 2 * MF_SLOT + wave * MF_HREG);
+  auto issue_h = [&](int c) __attribute__((always_inline)) {
+    const void* gh = p.h13 + (int64_t)c * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mf_dma(gh, hoff[j], hreg_lds + j * 1024);
+  };
+
+  // ---- Request stream and waits.  Loads retire in order, so "s_waitcnt vmcnt(N)" with N = the number of YOUNGER loads of this wave says
+  //      that a given request has landed (outstanding stores only make it wait longer, never less).  Per chunk c, per wave:
+  //        B1(c): wait W2T(c), barrier   | request W13T(c + 1) [12]  | dg^T = W2T_c dy^T        | wait h13 tile(c) | SwiGLU', dh13 out [4 stores]
+  //        B2(c): wait W13T(c), barrier  | request W2T(c + 2) [6], h13 tile(c + 1) [4]          | dx^T += W13T_c dh13^T
+  //      so W2T is requested 1.6 chunks ahead of its use, W13T 1.4, the h13 tile one; the younger-load counts are
+  //        at B1(c): tile(c-1) 4 + W13T(c) 12 + W2T(c+1) 6 + tile(c) 4 = 26;   before the SwiGLU': W13T(c+1) = 12;
+  //        at B2(c): W2T(c+1) 6 + tile(c) 4 + W13T(c+1) 12 = 22.
+  //      Past the last chunk the requests are repeated with the last chunk's addresses (into slots nobody reads any more), so that the
+  //      counts hold to the end.
+  const int last = nchunks - 1;
+  issue_w2(0, 0);
+  issue_w13(0, 0);
+  issue_w2(last < 1 ? last : 1, 1);
+  issue_h(0);
+  // ---- stationary B operand of the first product: dy^T fragments of this lane's token (k = 16 t + 8 lh .. + 8)
+  Frag<T> dyf[MF_D / 16];
+  const T* dyrow = p.dy + (int64_t)mc * p.lddy + 8 * lh;
+#pragma unroll
+  for (int t = 0; t < MF_D / 16; ++t) frag_load_contig<T>(dyf[t], dyrow + 16 * t);
+  f32x16 dx[MF_D / 32];
+#pragma unroll
+  for (int t = 0; t < MF_D / 32; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dx[t][r] = 0.0f;
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // B1(0): everything requested so far (and the dy fragments) has landed
+
+  for (int c = 0; c < nchunks; ++c) {
+    const char* w2img = w2slot(c & 1);
+    const char* w13img = w13slot(c & 1);
+    if (c > 0) asm volatile("s_waitcnt vmcnt(26)\n\ts_barrier" ::: "memory");              // B1(c)
+#ifndef MF_ABL_NODMA                                    // timing builds only (wrong results)
+    issue_w13(c + 1 < nchunks ? c + 1 : last, (c + 1) & 1);     // that slot was last read by the second product of chunk c - 1
+#endif
+    // ---- dg^T = W2T_c dy^T: 24 MFMAs, the A fragments read four ahead (one wave per SIMD: nobody else hides the LDS latency)
+    f32x16 dg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dg[r] = 0.0f;
+    Frag<T> fa[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) nt_frag<T>(fa[0][s], w2img, li, s, lh);
+#pragma unroll
+    for (int s6 = 0; s6 < MF_KT; ++s6) {
+      if (s6 + 1 < MF_KT) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nt_frag<T>(fa[(s6 + 1) & 1][s], w2img + (s6 + 1) * 32 * ROW_BYTES, li, s, lh);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mma32<T>(dg, fa[s6 & 1][s], dyf[s6 * 4 + s]);
+      // the next group's four LDS reads FIRST, then this group's four MFMAs (left alone hipcc puts the reads behind three of the MFMAs
+      // and waits for them 32 cycles later)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#ifndef MF_ABL_NOLD
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // this wave's h13 tile of chunk c has landed (wave-private: no barrier)
+#endif
+    // ---- SwiGLU derivative: lane (token, lh) holds dg of the hidden units 4 (2 s + lh) + e, e = 0..3, in dg[4 s + e]
+    Frag<T> bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hreg + nt_off(li, 2 * s + lh));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a1 = (float)hv[e], a3 = (float)hv[4 + e], g = dg[4 * s + e];
+#ifdef MF_ABL_NOMATH
+        bf[s].v[e] = (T)(g + a1);
+        bf[s].v[4 + e] = (T)(g + a3);
+#else
+        const float sg = mf_sigmoid<true>(a1), ds = g * sg;
+        bf[s].v[e] = (T)(ds * a3 * (1.0f + a1 * (1.0f - sg)));
+        bf[s].v[4 + e] = (T)(ds * a1);
+#endif
+      }
+      *reinterpret_cast<bf16x8*>(hreg + nt_off(li, 2 * s + lh)) = bf[s].v;       // the place this lane just read
+    }
+    // dh13 leaves as whole row segments (eight lanes per row): read back here (LDS instructions of a wave execute in order: these reads see
+    // the writes above), stored behind the barrier so that the LDS latency hides in the wait
+    bf16x8 rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const bf16x8*>(hreg + nt_off(j * 8 + row8, ch));
+    asm volatile("s_waitcnt vmcnt(22)\n\ts_barrier" ::: "memory");               // B2(c): W13T(c) has landed; everyone is done with W2T(c)
+#ifndef MF_ABL_NODMA
+    issue_w2(c + 2 < nchunks ? c + 2 : last, c & 1);
+#endif
+#ifndef MF_ABL_NOST
+    if (wave_full) {                                      // wave-uniform: no per-lane predicate (and no branch per store) for whole tiles
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fk_st<true>(reinterpret_cast<bf16x8*>(hdst[j] + c * 64), rb[j]);      // written once, read by the weight-gradient GEMMs later
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (hrow_ok[j]) fk_st<true>(reinterpret_cast<bf16x8*>(hdst[j] + c * 64), rb[j]);
+    }
+#else
+    asm volatile("" ::"v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
+#endif
+#ifndef MF_ABL_NOLD
+    issue_h(c + 1 < nchunks ? c + 1 : last);              // the tile is free: its read-back sits in registers (the stores above waited for it)
+#endif
+    // ---- dx^T += W13T_c dh13^T: 48 MFMAs, fragments of feature tile t + 1 read while tile t multiplies
+    constexpr int NT12 = MF_D / 32;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) nt_frag<T>(fa[0][s], w13img, li, s, lh);
+#pragma unroll
+    for (int t = 0; t < NT12; ++t) {
+      if (t + 1 < NT12) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nt_frag<T>(fa[(t + 1) & 1][s], w13img, 32 * (t + 1) + li, s, lh);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mma32<T>(dx[t], fa[t & 1][s], bf[s]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the repeated requests of the tail have landed: the LDS is free for the dx staging
+
+  // ---- dx: accumulators (lane = token, 4 consecutive features per register group) -> bf16 rows staged in LDS -> 16-byte row stores
+  char* stg = smem + wave * 32 * MF_ROWP;
+#pragma unroll
+  for (int t = 0; t < MF_D / 32; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (T)dx[t][4 * g + e];
+      *reinterpret_cast<bf16x4*>(stg + li * MF_ROWP + (32 * t + 8 * g + 4 * lh) * 2) = v;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private staging: no barrier needed
+  if (lane < MF_D / 8) {
+    const int m0 = blockIdx.x * MF_TOK + wave * 32;
+    for (int r = 0; r < 32; ++r) {
+      if (m0 + r >= p.M) break;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + r * MF_ROWP + lane * 16);
+      fk_st<true>(reinterpret_cast<bf16x8*>(p.dx + (int64_t)(m0 + r) * p.lddx + lane * 8), v);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int fk_mlp_bwd_fused(const void* dY, int64_t lddy, const void* W2T, int64_t ldw2t, const void* H13, int64_t ldh, const void* W13T,
+                                int64_t ldw13t, void* dH13, int64_t lddh, void* dX, int64_t lddx, int64_t M, int64_t H, int64_t D, int dtype,
+                                void* stream) {
+  FK_CHECK_ARG(dtype == FK_BF16, "fk_mlp_bwd_fused: bf16 only (dtype %d)", dtype);
+  FK_CHECK_ARG(D == MF_D, "fk_mlp_bwd_fused: model dimension %lld (built for %d)", (long long)D, MF_D);
+  FK_CHECK_ARG(M > 0 && M < (1LL << 31) && H > 0 && H % 32 == 0 && H < (1 << 24), "fk_mlp_bwd_fused: bad shape M=%lld H=%lld", (long long)M, (long long)H);
+  FK_CHECK_ARG(dY && W2T && H13 && W13T && dH13 && dX, "fk_mlp_bwd_fused: null pointer");
+  FK_CHECK_ARG(lddy % 8 == 0 && ldw2t % 8 == 0 && ldh % 8 == 0 && ldw13t % 8 == 0 && lddh % 8 == 0 && lddx % 8 == 0 && lddy >= D && ldw2t >= D &&
+                   ldh >= 2 * H && lddh >= 2 * H && ldw13t >= 2 * H && lddx >= D,
+               "fk_mlp_bwd_fused: leading dimensions must be multiples of 8 elements and cover their rows");
+  FK_CHECK_ARG(M * ldh * 2 < (1LL << 32) && (int64_t)D * ldw13t * 2 < (1LL << 32) && 32 * ldw2t * 2 < (1LL << 32),
+               "fk_mlp_bwd_fused: the h13 block must be addressable with 32-bit byte offsets (M * ldh < 2^31 elements)");
+  FK_CHECK_ARG((((uintptr_t)dY | (uintptr_t)W2T | (uintptr_t)H13 | (uintptr_t)W13T | (uintptr_t)dH13 | (uintptr_t)dX) & 15) == 0,
+               "fk_mlp_bwd_fused: pointers must be 16-byte aligned");
+  MlpBwdArgs a{(const bf16_t*)dY, (const bf16_t*)W2T, (const bf16_t*)H13, (const bf16_t*)W13T, (bf16_t*)dH13, (bf16_t*)dX,
+               lddy, ldw2t, ldh, ldw13t, lddh, lddx, (int)M, (int)H};
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS) == hipSuccess);
+  (void)once;
+  hipLaunchKernelGGL(mlp_bwd_fused_kernel, dim3((unsigned)fk_cdiv(M, MF_TOK)), dim3(MF_NW * 64), MF_LDS, (hipStream_t)stream, a);
+  FK_CHECK_LAUNCH("fk_mlp_bwd_fused");
+  return FK_OK;
+}

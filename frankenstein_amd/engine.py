@@ -609,6 +609,9 @@ class CrossAttnBranch(torch.autograd.Function):
         return dx.view(B, T, d), dctx.view(B, Nc, d), dg, db, dqw, dkw, dvw, dpw, None
 
 
+_MLP_BWD_FUSED = os.environ.get("FK_MLP_BWD_FUSED", "1") != "0"
+
+
 class MlpBranch(torch.autograd.Function):
     """y = [x +] W2 act(W1 [LN](x)):  SwiGLU (w1,w3 -> silu*gate -> w2, models/brainformer.py:115-124,244) when
     ``gate_w`` is given, GELU-erf MLP with biases (models/gpt2_model.py:87-92,105) otherwise."""
@@ -660,7 +663,13 @@ class MlpBranch(torch.autograd.Function):
         dyd = dy2 if drop is None else K.dropout(dy2, drop[0], drop[1], drop[2])         # the gradient behind the dropout
         (ddown,) = wgrad(dyd, g, [down_w])
         ddb = K.colsum(dyd) if has_db else None
-        if ctx.fused:   # down-projection dgrad + SwiGLU backward in one kernel; dg is never materialised
+        if (ctx.fused and _MLP_BWD_FUSED and dyd.dtype == torch.bfloat16 and d == 384 and g.shape[1] % 32 == 0 and dyd.shape[0] >= 4096
+                and dyd.shape[0] * a.shape[1] * 2 < 2 ** 32):
+            # both products of the data-gradient chain in ONE attention-shaped launch, dh13 handed over in registers: the same bits as the
+            # two launches below, -0.3 ... -0.4 ms per cfg2 step; FK_MLP_BWD_FUSED=0 keeps the two launches
+            da, dh = K.mlp_bwd_fused(dyd, shadow([down_w], transpose=True), a, shadow_swiglu(up_w, gate_w, transpose=True))
+            dups = wgrad(da, h, [up_w, gate_w], swiglu_interleaved=True)
+        elif ctx.fused:   # down-projection dgrad + SwiGLU backward in one kernel; dg is never materialised
             da = K.gemm_nt_dswiglu(dyd, shadow([down_w], transpose=True), a)
             dh = K.gemm_nt(da, shadow_swiglu(up_w, gate_w, transpose=True))
             dups = wgrad(da, h, [up_w, gate_w], swiglu_interleaved=True)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FK_VERSION 301
+#define FK_VERSION 302
 
 #define FK_OK 0
 #define FK_EINVAL (-1)       /* bad shape / dtype / alignment / null pointer */
@@ -69,6 +69,14 @@ int fk_gemm_nt_swiglu(const void* A, int64_t lda, const void* W13, int64_t ldb, 
                       int64_t ldg, int64_t M, int64_t H, int64_t K, int dtype, void* stream);
 int fk_gemm_nt_dswiglu(const void* dY, int64_t lda, const void* W2T, int64_t ldb, const void* H13, int64_t ldh, void* dH13,
                        int64_t lddh, int64_t M, int64_t H, int64_t K, int dtype, void* stream);
+/* fk_mlp_bwd_fused (ABI 302): the two calls above that make up the data-gradient chain of the SwiGLU MLP's backward
+ *   (autograd of models/brainformer.py:119-124) as ONE launch:   dg = dY W2T^T (never stored),   dH13 = SwiGLU'(H13) * dg (written once, for
+ *   the weight gradients),   dX[M,D] = dH13 W13T^T with dH13 taken from registers instead of being read back.  bf16, D = 384, H % 32 == 0;
+ *   W2T [H, D] and W13T [D, 2H] are the transposed shadows the two separate calls take.  Results are bit-identical to
+ *   fk_gemm_nt_dswiglu followed by fk_gemm_nt (same products, operand slots and summation order).                        */
+int fk_mlp_bwd_fused(const void* dY, int64_t lddy, const void* W2T, int64_t ldw2t, const void* H13, int64_t ldh, const void* W13T,
+                     int64_t ldw13t, void* dH13, int64_t lddh, void* dX, int64_t lddx, int64_t M, int64_t H, int64_t D, int dtype,
+                     void* stream);
 /* fk_gemm_tn: C[N1,N2] (fp32) (+)= sum_m A[m,N1] * B[m,N2]  — the weight gradient dW = dY^T X of a Linear
  *   (autograd of the call sites above).  Split over m with deterministic slab reduction.                     */
 size_t fk_gemm_tn_workspace_bytes(int64_t M, int64_t N1, int64_t N2, int dtype);

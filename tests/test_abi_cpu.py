@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_symbol(built):
     for s in declared_symbols():
         assert hasattr(h, s), f"{s} declared in include/franken_hip.h but not exported"
     lib = _lib.lib()
-    assert lib.fk_version() == 301
+    assert lib.fk_version() == 302
     assert lib.fk_last_error() is not None
 
 
@@ -44,7 +44,7 @@ def test_graft_entry_build_runs(built):
     g.build()
     from frankenstein_amd import _lib
     txt = (ROOT / "include" / "franken_hip.h").read_text()
-    assert _lib.lib().fk_version() == int(re.search(r"#define FK_VERSION (\d+)", txt).group(1)) == 301
+    assert _lib.lib().fk_version() == int(re.search(r"#define FK_VERSION (\d+)", txt).group(1)) == 302
 
 
 def test_argument_validation_needs_no_gpu(built):

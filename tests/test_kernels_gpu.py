@@ -662,6 +662,35 @@ DENSE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [(256, 64), (1000, 96), (4096 + 37, 1536), (128, 32)])
+def test_mlp_backward_fused_equals_the_two_gemm_kernels_bit_for_bit(K, case):
+    """fk_mlp_bwd_fused (the SwiGLU MLP's data-gradient chain in one launch, token on the lane, dh13 handed from the first product to the
+    second in registers) against the two launches it replaces — fk_gemm_nt_dswiglu, then fk_gemm_nt on the dh13 it wrote: same products,
+    operand slots and summation order, so dh13 AND dx must be identical bits (ragged row counts: the last workgroup and wave are partial),
+    and both against the fp32 oracle formula."""
+    M, H = case
+    d = 384
+    g = torch.Generator().manual_seed(M + H)
+    dy = (torch.randn(M, d, generator=g) * 0.5).bfloat16().cuda()
+    h13 = (torch.randn(M, 2 * H, generator=g)).bfloat16().cuda()
+    w2t = (torch.randn(H, d, generator=g) / math.sqrt(d)).bfloat16().cuda()
+    w13t = (torch.randn(d, 2 * H, generator=g) / math.sqrt(H)).bfloat16().cuda()
+    dh_ref = K.gemm_nt_dswiglu(dy, w2t, h13)
+    dx_ref = K.gemm_nt(dh_ref, w13t)
+    dh, dx = K.mlp_bwd_fused(dy, w2t, h13, w13t)
+    assert torch.equal(dh, dh_ref), float((dh.float() - dh_ref.float()).abs().max())
+    assert torch.equal(dx, dx_ref), float((dx.float() - dx_ref.float()).abs().max())
+    # the oracle's formula in fp32 (interleaved hidden layout: per 4 units 4 x h1, then 4 x h3)
+    dg = dy.float().cpu() @ w2t.float().cpu().t()
+    hh = h13.float().cpu().view(M, H // 4, 2, 4)
+    a1, a3 = hh[:, :, 0].reshape(M, H), hh[:, :, 1].reshape(M, H)
+    sg = torch.sigmoid(a1)
+    d1, d3 = dg * sg * a3 * (1 + a1 * (1 - sg)), dg * sg * a1
+    want = torch.stack([d1.view(M, H // 4, 4), d3.view(M, H // 4, 4)], dim=2).reshape(M, 2 * H)
+    torch.testing.assert_close(dh.float().cpu(), want, atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(dx.float().cpu(), dh.float().cpu() @ w13t.float().cpu().t(), atol=3e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", DENSE_CASES)
 def test_attention_dense_boolean_mask(K, dtype, case):

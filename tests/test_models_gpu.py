@@ -754,6 +754,36 @@ def test_block_without_rope_takes_the_prescaled_kernels_in_bf16(masked, monkeypa
         assert cos(g1[k], g2[k]) > 0.995, k
 
 
+def test_mlp_branch_with_the_fused_backward_kernel_gives_the_same_bits(monkeypatch):
+    """engine._MLP_BWD_FUSED (default on; FK_MLP_BWD_FUSED=0 switches it off): the SwiGLU MLP's backward through fk_mlp_bwd_fused
+    instead of fk_gemm_nt_dswiglu + fk_gemm_nt — a d = 384 block in bf16 mode, ragged token count: output, input gradient and every
+    parameter gradient identical."""
+    from frankenstein_amd import engine as E
+    from frankenstein_amd.models import brainformer as bf
+    cfg = bf.MAEConfig(window_size=8, n_electrodes=25, patch_size=4, dim=384, n_layers=1, head_dim=64, hidden_dim=160, n_heads=6, n_kv_heads=6)
+    blk = bf.Block(cfg)
+    st = synth.make_state({k: tuple(v.shape) for k, v in blk.state_dict().items()})
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    blk.cuda()
+    g = torch.Generator().manual_seed(3)
+    x, dy = torch.randn(3, 1500, 384, generator=g), torch.randn(3, 1500, 384, generator=g)       # 4500 rows: over the routing threshold, ragged
+    fa.set_compute_dtype("bf16")
+    try:
+        outs = []
+        for flag in (False, True):
+            monkeypatch.setattr(E, "_MLP_BWD_FUSED", flag)
+            blk.zero_grad(set_to_none=True)
+            xd = x.cuda().requires_grad_(True)
+            out = blk(xd, attn_mask=None, rope=None)
+            (out.float() * dy.cuda()).sum().backward()
+            outs.append((out.detach().clone(), xd.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()}))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for k in outs[0][2]:
+            assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+    finally:
+        fa.set_compute_dtype("fp32")
+
+
 def test_run_train_model_end_to_end(tmp_path):
     """The reference's driver contract (utils/train_utils.py:93-185): loaders -> steps -> eval on an interval ->
     best-val safetensors checkpoint that loads back into a fresh model (same state-dict keys)."""

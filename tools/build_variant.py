@@ -20,7 +20,7 @@ tmp.mkdir(parents=True, exist_ok=True)
 
 def cc(s):
     o = tmp / (s + ".o")
-    r = subprocess.run([B.HIPCC, *B.FLAGS, *extra, "-c", str(B.CSRC / s), "-o", str(o)], capture_output=True, text=True)
+    r = subprocess.run([B.HIPCC, *B.flags_for(s), *extra, "-c", str(B.CSRC / s), "-o", str(o)], capture_output=True, text=True)
     if r.returncode:
         raise SystemExit(r.stderr[-3000:])
     return o

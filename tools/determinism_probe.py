@@ -31,6 +31,7 @@ cases = {
     "gemm_nt down+res": lambda: K.gemm_nt(gg, w2, None, residual=dy),
     "gemm_nt_dswiglu": lambda: K.gemm_nt_dswiglu(dy, w2t, h13),
     "gemm_nt d_up": lambda: K.gemm_nt(dh13, w13t),
+    "mlp_bwd_fused": lambda: torch.cat([t_.reshape(-1) for t_ in K.mlp_bwd_fused(dy, w2t, h13, w13t)]),
     "gemm_nt d_qkv": lambda: K.gemm_nt(qkv, w_qkvt),
     "gemm_nt fp32 out": lambda: K.gemm_nt(x[:16384], w_qkv, out_dtype=torch.float32),
     "gemm_nt fp32 out 256-tile": lambda: K.gemm_nt(x[:16384], w13, out_dtype=torch.float32),
@@ -57,6 +58,10 @@ checks = {
     "gemm_tn dW_up vs rocBLAS": (K.gemm_tn(dh13, x), dh13.float().t() @ xf),
     "gemm_tn dW_qkv vs rocBLAS": (K.gemm_tn(qkv, x), qkv.float().t() @ xf),
 }
+fd, fx = K.mlp_bwd_fused(dy, w2t, h13, w13t)          # at full size: the fused data-gradient chain IS the two launches it replaces, bit for bit
+d_two = K.gemm_nt_dswiglu(dy, w2t, h13)
+print(f"{'mlp_bwd_fused vs dswiglu + d_up (bits)':40s} {'OK' if torch.equal(fd, d_two) and torch.equal(fx, K.gemm_nt(d_two, w13t)) else 'MISMATCH'}", flush=True)
+del fd, fx, d_two
 h13o, go = K.gemm_nt_swiglu(x, w13)
 h13r = xf @ w13.float().t()
 checks["gemm_nt_swiglu h13 vs rocBLAS"] = (h13o, h13r)

@@ -24,6 +24,7 @@ cases = {
     "nt dswiglu   N=1536 K=384": (lambda: K.gemm_nt_dswiglu(dy, w2t, h13), 2 * M * 1536 * 384, M * (384 + 3072 * 2) * 2),
     "nt d_up      N=384  K=3072": (lambda: K.gemm_nt(dh13, w13t), 2 * M * 384 * 3072, M * (3072 + 384) * 2),
     "nt d_qkv     N=384  K=1152": (lambda: K.gemm_nt(qkv, w_qkvt), 2 * M * 384 * 1152, M * (1152 + 384) * 2),
+    "fused dswiglu + d_up (one launch)": (lambda: K.mlp_bwd_fused(dy, w2t, h13, w13t), 2 * M * 1536 * 384 + 2 * M * 384 * 3072, M * (384 + 3072 * 2 + 384) * 2),
     "tn dW_qkv    1152x384": (lambda: K.gemm_tn(qkv, x), 2 * M * 1152 * 384, M * (1152 + 384) * 2),
     "tn dW_up     3072x384": (lambda: K.gemm_tn(dh13, x), 2 * M * 3072 * 384, M * (3072 + 384) * 2),
     "tn dW_down   384x1536": (lambda: K.gemm_tn(dy, gg), 2 * M * 384 * 1536, M * (1536 + 384) * 2),

@@ -23,7 +23,7 @@ def compile_isa(src: str, outdir: Path):
     """device-only assembly + resource remarks of csrc/<src> with the build's own flags -> (path of the .s, remark text)"""
     from frankenstein_amd import build as B
     out = Path(outdir) / (src + ".s")
-    cmd = [B.HIPCC, *B.FLAGS, "-S", "--cuda-device-only", f"-I{ROOT / 'include'}", "-Rpass-analysis=kernel-resource-usage",
+    cmd = [B.HIPCC, *B.flags_for(src), "-S", "--cuda-device-only", f"-I{ROOT / 'include'}", "-Rpass-analysis=kernel-resource-usage",
            "-o", str(out), str(B.CSRC / src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
