@@ -36,6 +36,15 @@ struct MlpBwdArgs {
   int M, H;
 };
 
+#ifndef MF_SPREAD
+#define MF_SPREAD 1        // 1: LDS-DMA requests placed one behind each MFMA group (-7 % per call, -0.44 ms per step); 0: in bursts
+#endif
+#ifndef MF_SPREAD_ST
+#define MF_SPREAD_ST 0
+#endif
+#ifndef MF_NT_DH13
+#define MF_NT_DH13 1
+#endif
 constexpr int MF_D = 384, MF_NW = 4, MF_TOK = MF_NW * 32;
 constexpr int MF_KT = MF_D / 64;                          // k-tile images of a W2T chunk (6)
 constexpr int MF_W2 = MF_KT * 32 * ROW_BYTES;            // 24 KiB
@@ -90,17 +99,25 @@ __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
   auto w2slot = [&](int i) -> char* { return smem + i * MF_W2; };
   auto w13slot = [&](int i) -> char* { return smem + 2 * MF_W2 + i * MF_W13; };
-  auto issue_w2 = [&](int c, int slot) __attribute__((always_inline)) {
+  // one request (piece j of this wave's share) at a time: inside the chunk loop they are placed one behind each MFMA group (MF_SPREAD), so
+  // that a wave without a partner on its SIMD issues them in the shadow of its own matrix work instead of in bursts
+  auto dma_w2 = [&](int c, int slot, int j) __attribute__((always_inline)) {
     const void* g2 = p.w2t + (int64_t)c * 32 * p.ldw2t;
     const unsigned d0 = __builtin_amdgcn_readfirstlane(lds0 + slot * MF_W2 + wave * (MF_W2 / MF_NW));
-#pragma unroll
-    for (int j = 0; j < MF_W2 / 1024 / MF_NW; ++j) mf_dma(g2, off2[j], d0 + j * 1024);
+    mf_dma(g2, off2[j], d0 + j * 1024);
   };
-  auto issue_w13 = [&](int c, int slot) __attribute__((always_inline)) {
+  auto dma_w13 = [&](int c, int slot, int j) __attribute__((always_inline)) {
     const void* g13 = p.w13t + (int64_t)c * 64;
     const unsigned d0 = __builtin_amdgcn_readfirstlane(lds0 + 2 * MF_W2 + slot * MF_W13 + wave * (MF_W13 / MF_NW));
+    mf_dma(g13, off13[j], d0 + j * 1024);
+  };
+  auto issue_w2 = [&](int c, int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < MF_W13 / 1024 / MF_NW; ++j) mf_dma(g13, off13[j], d0 + j * 1024);
+    for (int j = 0; j < MF_W2 / 1024 / MF_NW; ++j) dma_w2(c, slot, j);
+  };
+  auto issue_w13 = [&](int c, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < MF_W13 / 1024 / MF_NW; ++j) dma_w13(c, slot, j);
   };
   // ---- the wave's h13 rows of a chunk (32 tokens x 64 interleaved columns = 4 KiB) also arrive by LDS-DMA, into a wave-private tile
   //      with the image's swizzle; the lane reads its four 16-byte pieces from there, the dh13 pieces go back into the SAME places and
@@ -120,10 +137,10 @@ __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs
     hdst[j] = p.dh13 + (int64_t)(hrow_ok[j] ? mr : p.M - 1) * p.lddh + (ch << 3);                                 // store: logical piece ch of row r
   }
   const unsigned hreg_lds = __builtin_amdgcn_readfirstlane(lds0 + 2 * MF_SLOT + wave * MF_HREG);
+  auto dma_h = [&](int c, int j) __attribute__((always_inline)) { mf_dma(p.h13 + (int64_t)c * 64, hoff[j], hreg_lds + j * 1024); };
   auto issue_h = [&](int c) __attribute__((always_inline)) {
-    const void* gh = p.h13 + (int64_t)c * 64;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) mf_dma(gh, hoff[j], hreg_lds + j * 1024);
+    for (int j = 0; j < 4; ++j) dma_h(c, j);
   };
 
   // ---- Request stream and waits.  Loads retire in order, so "s_waitcnt vmcnt(N)" with N = the number of YOUNGER loads of this wave says
@@ -156,8 +173,9 @@ __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs
     const char* w2img = w2slot(c & 1);
     const char* w13img = w13slot(c & 1);
     if (c > 0) asm volatile("s_waitcnt vmcnt(26)\n\ts_barrier" ::: "memory");              // B1(c)
-#ifndef MF_ABL_NODMA                                    // timing builds only (wrong results)
-    issue_w13(c + 1 < nchunks ? c + 1 : last, (c + 1) & 1);     // that slot was last read by the second product of chunk c - 1
+    const int cn1 = c + 1 < nchunks ? c + 1 : last, cn2 = c + 2 < nchunks ? c + 2 : last;
+#if !defined(MF_ABL_NODMA) && !MF_SPREAD                // MF_ABL_*: timing builds only (wrong results)
+    issue_w13(cn1, (c + 1) & 1);                          // that slot was last read by the second product of chunk c - 1
 #endif
     // ---- dg^T = W2T_c dy^T: 24 MFMAs, the A fragments read four ahead (one wave per SIMD: nobody else hides the LDS latency)
     f32x16 dg;
@@ -174,6 +192,10 @@ __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) mma32<T>(dg, fa[s6 & 1][s], dyf[s6 * 4 + s]);
+#if !defined(MF_ABL_NODMA) && MF_SPREAD
+      dma_w13(cn1, (c + 1) & 1, 2 * s6);                  // W13T(c + 1): two of this wave's twelve requests behind each of the six groups
+      dma_w13(cn1, (c + 1) & 1, 2 * s6 + 1);
+#endif
       // the next group's four LDS reads FIRST, then this group's four MFMAs (left alone hipcc puts the reads behind three of the MFMAs
       // and waits for them 32 cycles later)
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -208,23 +230,27 @@ __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const bf16x8*>(hreg + nt_off(j * 8 + row8, ch));
     asm volatile("s_waitcnt vmcnt(22)\n\ts_barrier" ::: "memory");               // B2(c): W13T(c) has landed; everyone is done with W2T(c)
-#ifndef MF_ABL_NODMA
-    issue_w2(c + 2 < nchunks ? c + 2 : last, c & 1);
+#if !defined(MF_ABL_NODMA) && !MF_SPREAD
+    issue_w2(cn2, c & 1);
 #endif
 #ifndef MF_ABL_NOST
     if (wave_full) {                                      // wave-uniform: no per-lane predicate (and no branch per store) for whole tiles
+#if !MF_SPREAD_ST
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fk_st<true>(reinterpret_cast<bf16x8*>(hdst[j] + c * 64), rb[j]);      // written once, read by the weight-gradient GEMMs later
+      for (int j = 0; j < 4; ++j) fk_st<MF_NT_DH13 != 0>(reinterpret_cast<bf16x8*>(hdst[j] + c * 64), rb[j]);      // written once, read by the weight-gradient GEMMs later
+#else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3])::"memory");        // the read-back is in registers: the tile is free
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (hrow_ok[j]) fk_st<true>(reinterpret_cast<bf16x8*>(hdst[j] + c * 64), rb[j]);
+        if (hrow_ok[j]) fk_st<MF_NT_DH13 != 0>(reinterpret_cast<bf16x8*>(hdst[j] + c * 64), rb[j]);
     }
 #else
     asm volatile("" ::"v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
 #endif
-#ifndef MF_ABL_NOLD
-    issue_h(c + 1 < nchunks ? c + 1 : last);              // the tile is free: its read-back sits in registers (the stores above waited for it)
+#if !defined(MF_ABL_NOLD) && !MF_SPREAD
+    issue_h(cn1);                                         // the tile is free: its read-back sits in registers (the stores above waited for it)
 #endif
     // ---- dx^T += W13T_c dh13^T: 48 MFMAs, fragments of feature tile t + 1 read while tile t multiplies
     constexpr int NT12 = MF_D / 32;
@@ -238,6 +264,17 @@ __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) mma32<T>(dx[t], fa[t & 1][s], bf[s]);
+#if MF_SPREAD                                             // W2T(c + 2) behind the first six groups, then the h13 tile of chunk c + 1 (same order as the bursts: the counts hold)
+#ifndef MF_ABL_NODMA
+      if (t < 6) dma_w2(cn2, c & 1, t);
+#endif
+#ifndef MF_ABL_NOLD
+      if (t >= 6 && t < 10) dma_h(cn1, t - 6);
+#endif
+#if MF_SPREAD_ST && !defined(MF_ABL_NOST)
+      if (wave_full && t >= 6 && t < 10) fk_st<MF_NT_DH13 != 0>(reinterpret_cast<bf16x8*>(hdst[t - 6] + c * 64), rb[t - 6]);
+#endif
+#endif
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       __builtin_amdgcn_sched_barrier(0);
