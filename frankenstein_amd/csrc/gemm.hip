@@ -1569,6 +1569,9 @@ int colsum_blocks(int64_t rows) {
 
 }  // namespace
 
+bool fk_mlp_up_fused_ok(int64_t M, int64_t H, int64_t K, int64_t lda, int64_t ldb, int64_t ldh, int64_t ldg, int dtype);      // mlp_fused.hip
+int fk_mlp_up_fused_launch(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G, int64_t ldg, int64_t M, int64_t H, void* stream);
+
 extern "C" {
 
 struct RopeSpec { const float* table; int64_t bs; int T, off, D, cols; int qcols; int64_t qoff; };
@@ -1677,6 +1680,9 @@ int fk_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void
 int fk_gemm_nt_swiglu(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G,
                       int64_t ldg, int64_t M, int64_t H, int64_t K, int dtype, void* stream) {
   FK_CHECK_ARG(H > 0 && H % 4 == 0, "fk_gemm_nt_swiglu: hidden size must be a multiple of 4");
+  if (A && W13 && H13 && G && (((uintptr_t)A | (uintptr_t)W13 | (uintptr_t)H13 | (uintptr_t)G) & 15) == 0 && M > 0 &&
+      fk_mlp_up_fused_ok(M, H, K, lda, ldb, ldh, ldg, dtype))          // wide bf16 MLPs at d = 384: the token-on-the-lane kernel (mlp_fused.hip), same bits
+    return fk_mlp_up_fused_launch(A, lda, W13, ldb, H13, ldh, G, ldg, M, H, stream);
   return launch_nt("fk_gemm_nt_swiglu", A, lda, W13, ldb, H13, ldh, M, 2 * H, K, nullptr, nullptr, 0, 0, dtype, dtype, 1, G, ldg, stream);
 }
 

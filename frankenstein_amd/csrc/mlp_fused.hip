@@ -21,6 +21,7 @@
 // Built WITHOUT -amdgpu-mfma-vgpr-form (frankenstein_amd/build.py): the 208 accumulator registers live in the AGPR half, which is what
 // lets a wave keep 96 + 192 + 16 stationary registers at one wave per SIMD.
 #include "fk_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -304,7 +305,189 @@ __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs
   }
 }
 
+
+// ================================================================================================================================
+// The forward up-projection + SwiGLU of the same MLP with the token on the lane (what fk_gemm_nt_swiglu computes: H13 and G).
+//   Per wave 32 tokens with x^T stationary (96 registers); per chunk of 32 hidden units the W13 rows arrive as TWO 32-row tiles — tile 0
+//   the h1 rows, tile 1 the h3 rows of the same units — so that a lane finds h1 and h3 of a unit in the same register index of its two
+//   accumulators and silu(h1) * h3 happens in registers, without the fp32 staging sweep of the tiled kernel.  No accumulator outlives a
+//   chunk, so a wave needs ~200 registers: two waves per SIMD, eight per workgroup (256 tokens), and the weight chunk (48 KiB) is shared by
+//   twice as many tokens as in the backward kernel above.  h13 (16 bytes per lane and k-group) and g (8 bytes) leave through wave-private LDS
+//   tiles as whole row segments; the stores of chunk c are issued at the head of chunk c + 1 (from registers), i.e. BEFORE the next weight
+//   request, so that the end-of-chunk wait finds only requests that are a whole chunk old.  Same products and summation order as
+//   gemm_nt_ring2_kernel<.., 1>: bit-identical H13 and G.
+struct MlpUpArgs {
+  const bf16_t* x; const bf16_t* w13; bf16_t* h13; bf16_t* g;
+  int64_t ldx, ldw, ldh, ldg;
+  int M, H;
+};
+constexpr int MU_NW = 8, MU_TOK = MU_NW * 32;
+constexpr int MU_TILE = MF_KT * 32 * ROW_BYTES;          // one 32-row tile of a chunk: six k-tile images (24 KiB)
+constexpr int MU_SLOT = 2 * MU_TILE;                     // h1 rows + h3 rows (48 KiB)
+constexpr int MU_HT = 32 * ROW_BYTES, MU_GT = 32 * 64;   // per wave: h13 tile (32 x 128 B), g tile (32 x 64 B)
+constexpr int MU_LDS = 2 * MU_SLOT + MU_NW * (MU_HT + MU_GT);
+static_assert(MU_LDS <= 160 * 1024, "LDS of a CU");
+constexpr int MU_PIECES = MU_SLOT / 1024 / MU_NW;        // 6 requests per wave and chunk
+
+__global__ __launch_bounds__(MU_NW * 64, 2) void mlp_up_fused_kernel(MlpUpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using T = bf16_t;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0w = blockIdx.x * MU_TOK + wave * 32;
+  const int m = m0w + li, mc = m < p.M ? m : p.M - 1;
+  const bool wave_full = m0w + 32 <= p.M;
+  const int nchunks = p.H / 32, last = nchunks - 1;
+  const int row8 = lane >> 3, ch = lane & 7;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+
+  // requests: piece q = wave * 6 + j of the slot: tile q / 24 (0: h1 rows, 1: h3 rows), k-tile image (q % 24) >> 2, image rows (q & 3) * 8 + row8.
+  // Image row n of a tile is hidden unit 32 c + n: interleaved W13 row 8 (n / 4) + n % 4 (+ 4 for h3) of the chunk's 64 rows.
+  unsigned woff[MU_PIECES];
+#pragma unroll
+  for (int j = 0; j < MU_PIECES; ++j) {
+    const int q = wave * MU_PIECES + j, tile = q / 24, s6 = (q % 24) >> 2, n = (q & 3) * 8 + row8;
+    const int wrow = 8 * (n >> 2) + (n & 3) + 4 * tile;
+    woff[j] = (unsigned)((wrow * (int)p.ldw + s6 * 64 + ((ch ^ ((n >> 1) & 7)) << 3)) * 2);
+  }
+  auto issue_w = [&](int c, int slot) __attribute__((always_inline)) {
+    const void* gw = p.w13 + (int64_t)c * 64 * p.ldw;
+    const unsigned d0 = __builtin_amdgcn_readfirstlane(lds0 + slot * MU_SLOT + wave * (MU_SLOT / MU_NW));
+#pragma unroll
+    for (int j = 0; j < MU_PIECES; ++j) mf_dma(gw, woff[j], d0 + j * 1024);
+  };
+  char* htile = smem + 2 * MU_SLOT + wave * (MU_HT + MU_GT);
+  char* gtile = htile + MU_HT;
+  // output rows of the read-back: h13 eight lanes per row (8 rows per instruction), g four lanes per row (16 rows per instruction)
+  T* hdst[4];
+  T* gdst[2];
+  bool hok[4], gok[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int mr = m0w + j * 8 + row8;
+    hok[j] = mr < p.M;
+    hdst[j] = p.h13 + (int64_t)(hok[j] ? mr : p.M - 1) * p.ldh + (ch << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int mr = m0w + j * 16 + (lane >> 2);
+    gok[j] = mr < p.M;
+    gdst[j] = p.g + (int64_t)(gok[j] ? mr : p.M - 1) * p.ldg + ((lane & 3) << 3);
+  }
+
+  issue_w(0, 0);
+  Frag<T> xf[MF_D / 16];
+  const T* xrow = p.x + (int64_t)mc * p.ldx + 8 * lh;
+#pragma unroll
+  for (int t = 0; t < MF_D / 16; ++t) frag_load_contig<T>(xf[t], xrow + 16 * t);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // chunk 0 and the x fragments have landed
+
+  bf16x8 rbh[4] = {}, rbg[2] = {};
+  for (int c = 0; c < nchunks; ++c) {
+    const char* t0 = smem + (c & 1) * MU_SLOT;
+    const char* t1 = t0 + MU_TILE;
+    // the previous chunk's outputs (in registers since its read-back), then the next chunk's weights: the wait at the end of THIS chunk then
+    // only covers requests issued a whole chunk earlier
+    if (c > 0) {
+      if (wave_full) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fk_st<true>(reinterpret_cast<bf16x8*>(hdst[j] + (c - 1) * 64), rbh[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fk_st<true>(reinterpret_cast<bf16x8*>(gdst[j] + (c - 1) * 32), rbg[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (hok[j]) fk_st<true>(reinterpret_cast<bf16x8*>(hdst[j] + (c - 1) * 64), rbh[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (gok[j]) fk_st<true>(reinterpret_cast<bf16x8*>(gdst[j] + (c - 1) * 32), rbg[j]);
+      }
+    }
+    issue_w(c + 1 < nchunks ? c + 1 : last, (c + 1) & 1);          // that slot was read in chunk c - 1: every wave is past the barrier behind it
+    // ---- H^T = W13_c x^T: two accumulator tiles (h1 rows, h3 rows of the same 32 units), 48 MFMAs, fragments read one k-tile ahead
+    f32x16 a1, a3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a1[r] = 0.0f; a3[r] = 0.0f; }
+    Frag<T> f1[2][4], f3[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { nt_frag<T>(f1[0][s], t0, li, s, lh); nt_frag<T>(f3[0][s], t1, li, s, lh); }
+#pragma unroll
+    for (int s6 = 0; s6 < MF_KT; ++s6) {
+      if (s6 + 1 < MF_KT) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          nt_frag<T>(f1[(s6 + 1) & 1][s], t0 + (s6 + 1) * 32 * ROW_BYTES, li, s, lh);
+          nt_frag<T>(f3[(s6 + 1) & 1][s], t1 + (s6 + 1) * 32 * ROW_BYTES, li, s, lh);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        mma32<T>(a1, f1[s6 & 1][s], xf[s6 * 4 + s]);
+        mma32<T>(a3, f3[s6 & 1][s], xf[s6 * 4 + s]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- SwiGLU in registers: accumulator register 4 g + i of lane (token, lh) is hidden unit 8 g + 4 lh + i of the chunk in BOTH tiles;
+    //      the four units of a register group are interleaved hidden group 2 g + lh: one 16-byte piece of h13, one 8-byte piece of g
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x8 hp;
+      bf16x4 gp;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float h1 = a1[4 * g4 + i], h3 = a3[4 * g4 + i];
+        hp[i] = (T)h1;
+        hp[4 + i] = (T)h3;
+        gp[i] = (T)(h1 * mf_sigmoid<true>(h1) * h3);
+      }
+      const int q = 2 * g4 + lh;
+      *reinterpret_cast<bf16x8*>(htile + nt_off(li, q)) = hp;
+      *reinterpret_cast<bf16x4*>(gtile + li * 64 + ((((q >> 1) + li) & 3) << 4) + ((q & 1) << 3)) = gp;      // 16-byte chunks rotated by the row
+    }
+    // read back as whole row segments (LDS instructions of a wave execute in order); stored at the head of the next chunk
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rbh[j] = *reinterpret_cast<const bf16x8*>(htile + nt_off(j * 8 + row8, ch));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = j * 16 + (lane >> 2);
+      rbg[j] = *reinterpret_cast<const bf16x8*>(gtile + r * 64 + ((((lane & 3) + r) & 3) << 4));
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // chunk c + 1 has landed (requested a chunk ago, like the stores in front of it); everyone is done with this slot
+  }
+  if (wave_full) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fk_st<true>(reinterpret_cast<bf16x8*>(hdst[j] + last * 64), rbh[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fk_st<true>(reinterpret_cast<bf16x8*>(gdst[j] + last * 32), rbg[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (hok[j]) fk_st<true>(reinterpret_cast<bf16x8*>(hdst[j] + last * 64), rbh[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (gok[j]) fk_st<true>(reinterpret_cast<bf16x8*>(gdst[j] + last * 32), rbg[j]);
+  }
+}
+
 }  // namespace
+
+// the token-on-the-lane form of fk_gemm_nt_swiglu for the shapes it is built for (called from gemm.hip's entry point)
+bool fk_mlp_up_fused_ok(int64_t M, int64_t H, int64_t K, int64_t lda, int64_t ldb, int64_t ldh, int64_t ldg, int dtype) {
+  static const bool off = getenv("FK_MLP_UP_FUSED") != nullptr && getenv("FK_MLP_UP_FUSED")[0] == '0';
+  return !off && dtype == FK_BF16 && K == MF_D && H % 32 == 0 && M >= 32768 && M < (1LL << 31) && lda % 8 == 0 && ldb % 8 == 0 && ldh % 8 == 0 && ldg % 8 == 0 &&
+         64 * ldb * 2 < (1LL << 32);
+}
+int fk_mlp_up_fused_launch(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G, int64_t ldg, int64_t M, int64_t H,
+                           void* stream) {
+  MlpUpArgs a{(const bf16_t*)A, (const bf16_t*)W13, (bf16_t*)H13, (bf16_t*)G, lda, ldb, ldh, ldg, (int)M, (int)H};
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_up_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS) == hipSuccess);
+  (void)once;
+  hipLaunchKernelGGL(mlp_up_fused_kernel, dim3((unsigned)fk_cdiv(M, MU_TOK)), dim3(MU_NW * 64), MU_LDS, (hipStream_t)stream, a);
+  FK_CHECK_LAUNCH("fk_gemm_nt_swiglu (token-on-the-lane kernel)");
+  return FK_OK;
+}
 
 extern "C" int fk_mlp_bwd_fused(const void* dY, int64_t lddy, const void* W2T, int64_t ldw2t, const void* H13, int64_t ldh, const void* W13T,
                                 int64_t ldw13t, void* dH13, int64_t lddh, void* dX, int64_t lddx, int64_t M, int64_t H, int64_t D, int dtype,

@@ -663,7 +663,7 @@ class MlpBranch(torch.autograd.Function):
         dyd = dy2 if drop is None else K.dropout(dy2, drop[0], drop[1], drop[2])         # the gradient behind the dropout
         (ddown,) = wgrad(dyd, g, [down_w])
         ddb = K.colsum(dyd) if has_db else None
-        if (ctx.fused and _MLP_BWD_FUSED and dyd.dtype == torch.bfloat16 and d == 384 and g.shape[1] % 32 == 0 and dyd.shape[0] >= 4096
+        if (ctx.fused and _MLP_BWD_FUSED and dyd.dtype == torch.bfloat16 and d == 384 and g.shape[1] % 32 == 0 and dyd.shape[0] >= 32768          # 128 tokens per workgroup: below ~256 workgroups the two tiled GEMMs fill the chip better
                 and dyd.shape[0] * a.shape[1] * 2 < 2 ** 32):
             # both products of the data-gradient chain in ONE attention-shaped launch, dh13 handed over in registers: the same bits as the
             # two launches below, -0.3 ... -0.4 ms per cfg2 step; FK_MLP_BWD_FUSED=0 keeps the two launches

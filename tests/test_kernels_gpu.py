@@ -662,6 +662,28 @@ DENSE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [(32768, 64), (40_000 + 77, 1536), (33_000, 96)])
+def test_swiglu_up_projection_token_on_the_lane_equals_the_tiled_kernel_bit_for_bit(K, case):
+    """fk_gemm_nt_swiglu routes wide bf16 MLPs at d = 384 (M >= 32768) to the token-on-the-lane kernel (mlp_up_fused_kernel: SwiGLU in registers,
+    two waves per SIMD): H13 and G must be the bits of the tiled kernel, which the same entry point runs below the threshold — rows are
+    independent, so the reference is the same call on two row ranges under it — and both against the fp32 formula."""
+    M, H = case
+    d = 384
+    g = torch.Generator().manual_seed(M + 3 * H)
+    x = (torch.randn(M, d, generator=g) * 0.7).bfloat16().cuda()
+    w13 = (torch.randn(2 * H, d, generator=g) / math.sqrt(d)).bfloat16().cuda()
+    h13, gg = K.gemm_nt_swiglu(x, w13)
+    cut = M // 2
+    ref = [K.gemm_nt_swiglu(x[a:b], w13) for a, b in ((0, cut), (cut, M))]
+    h13_ref, g_ref = torch.cat([r[0] for r in ref]), torch.cat([r[1] for r in ref])
+    assert torch.equal(h13, h13_ref), float((h13.float() - h13_ref.float()).abs().max())
+    assert torch.equal(gg, g_ref), float((gg.float() - g_ref.float()).abs().max())
+    want = x.float().cpu() @ w13.float().cpu().t()
+    torch.testing.assert_close(h13.float().cpu(), want, atol=3e-2, rtol=2e-2)
+    hh = h13.float().cpu().view(M, H // 4, 2, 4)
+    torch.testing.assert_close(gg.float().cpu(), (torch.nn.functional.silu(hh[:, :, 0]) * hh[:, :, 1]).reshape(M, H), atol=3e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("case", [(256, 64), (1000, 96), (4096 + 37, 1536), (128, 32)])
 def test_mlp_backward_fused_equals_the_two_gemm_kernels_bit_for_bit(K, case):
     """fk_mlp_bwd_fused (the SwiGLU MLP's data-gradient chain in one launch, token on the lane, dh13 handed from the first product to the

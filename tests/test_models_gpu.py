@@ -766,7 +766,7 @@ def test_mlp_branch_with_the_fused_backward_kernel_gives_the_same_bits(monkeypat
     blk.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
     blk.cuda()
     g = torch.Generator().manual_seed(3)
-    x, dy = torch.randn(3, 1500, 384, generator=g), torch.randn(3, 1500, 384, generator=g)       # 4500 rows: over the routing threshold, ragged
+    x, dy = torch.randn(3, 11003, 384, generator=g), torch.randn(3, 11003, 384, generator=g)     # 33 009 rows: over the routing threshold, ragged
     fa.set_compute_dtype("bf16")
     try:
         outs = []
