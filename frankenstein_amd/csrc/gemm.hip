@@ -1569,6 +1569,8 @@ int colsum_blocks(int64_t rows) {
 
 }  // namespace
 
+bool fk_qkv_rope_fused_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const void* bias, int64_t T, int64_t D, int64_t rot_cols, int64_t q_cols, int dtype);
+int fk_qkv_rope_fused_launch(const void* A, int64_t lda, const void* W, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, const float* table, int64_t table_bs, int64_t T, int64_t pos_off, int64_t rot_cols, int64_t q_cols, int64_t q_off, void* stream);
 bool fk_mlp_up_fused_ok(int64_t M, int64_t H, int64_t K, int64_t lda, int64_t ldb, int64_t ldh, int64_t ldg, int dtype);      // mlp_fused.hip
 int fk_mlp_up_fused_launch(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G, int64_t ldg, int64_t M, int64_t H, void* stream);
 
@@ -1673,6 +1675,9 @@ int fk_gemm_nt_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     int64_t rot_cols, int64_t q_cols, int64_t q_table_off, int dtype, void* stream) {
   FK_CHECK_ARG(table && T > 0 && D > 0 && rot_cols >= 0, "fk_gemm_nt_rope: bad rope arguments");
   FK_CHECK_ARG(q_cols >= 0 && q_cols <= rot_cols && q_cols % 8 == 0 && q_table_off % 4 == 0, "fk_gemm_nt_rope: bad pre-scaled query table (q_cols %lld, offset %lld)", (long long)q_cols, (long long)q_table_off);
+  if (A && B && C && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)table) & 15) == 0 && M > 0 && pos_off >= 0 &&
+      fk_qkv_rope_fused_ok(M, N, K, lda, ldb, ldc, bias, T, D, rot_cols, q_cols, dtype))      // wide bf16 projections at d = 384, head_dim 64: the token-on-the-lane kernel (mlp_fused.hip), same bits
+    return fk_qkv_rope_fused_launch(A, lda, B, ldb, C, ldc, M, N, table, table_bs, T, pos_off, rot_cols, q_cols, q_table_off, stream);
   return launch_nt("fk_gemm_nt_rope", A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, 0, dtype, dtype, 0, nullptr, 0, stream,
                    RopeSpec{table, table_bs, (int)T, (int)pos_off, (int)D, (int)rot_cols, (int)q_cols, q_table_off});
 }

@@ -471,7 +471,168 @@ __global__ __launch_bounds__(MU_NW * 64, 2) void mlp_up_fused_kernel(MlpUpArgs p
   }
 }
 
+
+// ================================================================================================================================
+// The packed q | k | v projection with fused RoPE and pre-scaled queries (what fk_gemm_nt_rope computes) with the token on the lane.
+//   Same frame as mlp_up_fused_kernel: x^T stationary, two waves per SIMD, a chunk = 64 output columns = ONE head (two 32-column
+//   accumulator tiles), no accumulator outlives a chunk.  A lane owns 4 consecutive columns per register group = two complex pairs, so the
+//   rotation is register arithmetic; its (cos, sin) pairs — 16 bytes per register group, 8 groups per chunk, from the lane's own token row
+//   of the L2-resident table (the pre-scaled copy for the query heads) — are requested at the head of the chunk, in front of the next
+//   weight request, and waited for with a counted vmcnt (loads retire in order: 6 younger requests).  Same products, summation order and
+//   rotation arithmetic as gemm_nt_ring2_kernel<.., 3>: bit-identical output.
+struct QkvArgs {
+  const bf16_t* x; const bf16_t* w; bf16_t* out; const float* table;
+  int64_t ldx, ldw, ldo, table_bs, q_off;
+  int M, N, T, pos_off, rot_chunks, q_chunks;
+};
+constexpr int QK_LDS = 2 * MU_SLOT + MU_NW * MU_HT;
+static_assert(QK_LDS <= 160 * 1024, "LDS of a CU");
+
+__global__ __launch_bounds__(MU_NW * 64, 2) void qkv_rope_fused_kernel(QkvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using T = bf16_t;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0w = blockIdx.x * MU_TOK + wave * 32;
+  const int m = m0w + li, mc = m < p.M ? m : p.M - 1;
+  const bool wave_full = m0w + 32 <= p.M;
+  const int nchunks = p.N / 64, last = nchunks - 1;
+  const int row8 = lane >> 3, ch = lane & 7;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+
+  // requests: piece q = wave * 6 + j: tile q / 24 (columns 0..31 / 32..63 of the head), k-tile image (q % 24) >> 2, image rows (q & 3) * 8 + row8
+  unsigned woff[MU_PIECES];
+#pragma unroll
+  for (int j = 0; j < MU_PIECES; ++j) {
+    const int q = wave * MU_PIECES + j, tile = q / 24, s6 = (q % 24) >> 2, n = (q & 3) * 8 + row8;
+    woff[j] = (unsigned)(((32 * tile + n) * (int)p.ldw + s6 * 64 + ((ch ^ ((n >> 1) & 7)) << 3)) * 2);
+  }
+  auto issue_w = [&](int c, int slot) __attribute__((always_inline)) {
+    const void* gw = p.w + (int64_t)c * 64 * p.ldw;
+    const unsigned d0 = __builtin_amdgcn_readfirstlane(lds0 + slot * MU_SLOT + wave * (MU_SLOT / MU_NW));
+#pragma unroll
+    for (int j = 0; j < MU_PIECES; ++j) mf_dma(gw, woff[j], d0 + j * 1024);
+  };
+  char* htile = smem + 2 * MU_SLOT + wave * MU_HT;
+  T* odst[4];
+  bool ook[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int mr = m0w + j * 8 + row8;
+    ook[j] = mr < p.M;
+    odst[j] = p.out + (int64_t)(ook[j] ? mr : p.M - 1) * p.ldo + (ch << 3);
+  }
+  // this lane's (cos, sin) row: token mc is position pos_off + mc % T of sample mc / T; the lane's pairs start at pair 2 lh (4 floats per piece)
+  const float* trow = p.table + (int64_t)(mc / p.T) * p.table_bs + (int64_t)(p.pos_off + mc % p.T) * 64 + 4 * lh;
+
+  issue_w(0, 0);
+  Frag<T> xf[MF_D / 16];
+  const T* xrow = p.x + (int64_t)mc * p.ldx + 8 * lh;
+#pragma unroll
+  for (int t = 0; t < MF_D / 16; ++t) frag_load_contig<T>(xf[t], xrow + 16 * t);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // chunk 0 and the x fragments have landed
+
+  bf16x8 rb[4] = {};
+  for (int c = 0; c < nchunks; ++c) {
+    const char* t0 = smem + (c & 1) * MU_SLOT;
+    const char* t1 = t0 + MU_TILE;
+    if (c > 0) {                                          // the previous head's rows (in registers since its read-back)
+      if (wave_full) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fk_st<true>(reinterpret_cast<bf16x8*>(odst[j] + (c - 1) * 64), rb[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ook[j]) fk_st<true>(reinterpret_cast<bf16x8*>(odst[j] + (c - 1) * 64), rb[j]);
+      }
+    }
+    const bool rot = c < p.rot_chunks;                    // workgroup-uniform
+    f32x4 cs[8];
+    if (rot) {
+      const float* tq = trow + (c < p.q_chunks ? p.q_off : (int64_t)0);
+      asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
+                   "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
+                   "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
+                   "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224"
+                   : "=&v"(cs[0]), "=&v"(cs[1]), "=&v"(cs[2]), "=&v"(cs[3]), "=&v"(cs[4]), "=&v"(cs[5]), "=&v"(cs[6]), "=&v"(cs[7])
+                   : "v"(tq) : "memory");
+    }
+    issue_w(c + 1 < nchunks ? c + 1 : last, (c + 1) & 1);          // that slot was read in chunk c - 1: every wave is past the barrier behind it
+    // ---- two accumulator tiles of the head: 48 MFMAs, four fragments read ahead (tile 0 and tile 1 of a k-tile alternate)
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+    Frag<T> f[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) nt_frag<T>(f[0][s], t0, li, s, lh);
+#pragma unroll
+    for (int gq = 0; gq < 2 * MF_KT; ++gq) {               // group gq: tile gq & 1 of k-tile gq >> 1
+      if (gq + 1 < 2 * MF_KT) {
+        const char* nx = ((gq + 1) & 1 ? t1 : t0) + ((gq + 1) >> 1) * 32 * ROW_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nt_frag<T>(f[(gq + 1) & 1][s], nx, li, s, lh);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mma32<T>(acc[gq & 1], f[gq & 1][s], xf[(gq >> 1) * 4 + s]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (rot)      // the (cos, sin) pieces have landed: six younger requests (the next weight chunk) may still be in flight
+      asm volatile("s_waitcnt vmcnt(6)" : "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]), "+v"(cs[5]), "+v"(cs[6]), "+v"(cs[7])::"memory");
+    // ---- rotation in registers (the arithmetic of nt_epilogue's fused RoPE: explicit fma shape), rounding, 8-byte pieces into the row tile
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float v[4] = {acc[tl][4 * g4], acc[tl][4 * g4 + 1], acc[tl][4 * g4 + 2], acc[tl][4 * g4 + 3]};
+        if (rot) {
+          const f32x4 t = cs[4 * tl + g4];                 // (c0, s0, c1, s1) of the pairs 16 tl + 4 g4 + 2 lh, + 1
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float re = v[2 * j], im = v[2 * j + 1];
+            v[2 * j] = __builtin_fmaf(re, t[2 * j], -(im * t[2 * j + 1]));
+            v[2 * j + 1] = __builtin_fmaf(re, t[2 * j + 1], im * t[2 * j]);
+          }
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+        *reinterpret_cast<bf16x4*>(htile + nt_off(li, 4 * tl + g4) + 8 * lh) = o;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const bf16x8*>(htile + nt_off(j * 8 + row8, ch));
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // chunk c + 1 has landed (requested a chunk ago); everyone is done with this slot
+  }
+  if (wave_full) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fk_st<true>(reinterpret_cast<bf16x8*>(odst[j] + last * 64), rb[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ook[j]) fk_st<true>(reinterpret_cast<bf16x8*>(odst[j] + last * 64), rb[j]);
+  }
+}
+
 }  // namespace
+
+// the token-on-the-lane form of fk_gemm_nt_rope (called from gemm.hip's entry point)
+bool fk_qkv_rope_fused_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const void* bias, int64_t T, int64_t D, int64_t rot_cols,
+                          int64_t q_cols, int dtype) {
+  static const bool off = getenv("FK_QKV_FUSED") != nullptr && getenv("FK_QKV_FUSED")[0] == '0';
+  return !off && dtype == FK_BF16 && K == MF_D && D == 64 && N % 64 == 0 && rot_cols % 64 == 0 && q_cols % 64 == 0 && rot_cols <= N && !bias && M >= 32768 &&
+         M < (1LL << 31) && T > 0 && M % T == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && 64 * ldb * 2 < (1LL << 32);
+}
+int fk_qkv_rope_fused_launch(const void* A, int64_t lda, const void* W, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, const float* table,
+                             int64_t table_bs, int64_t T, int64_t pos_off, int64_t rot_cols, int64_t q_cols, int64_t q_off, void* stream) {
+  QkvArgs a{(const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, table, lda, ldb, ldc, table_bs, q_off, (int)M, (int)N, (int)T, (int)pos_off,
+            (int)(rot_cols / 64), (int)(q_cols / 64)};
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_rope_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QK_LDS) == hipSuccess);
+  (void)once;
+  hipLaunchKernelGGL(qkv_rope_fused_kernel, dim3((unsigned)fk_cdiv(M, MU_TOK)), dim3(MU_NW * 64), QK_LDS, (hipStream_t)stream, a);
+  FK_CHECK_LAUNCH("fk_gemm_nt_rope (token-on-the-lane kernel)");
+  return FK_OK;
+}
 
 // the token-on-the-lane form of fk_gemm_nt_swiglu for the shapes it is built for (called from gemm.hip's entry point)
 bool fk_mlp_up_fused_ok(int64_t M, int64_t H, int64_t K, int64_t lda, int64_t ldb, int64_t ldh, int64_t ldg, int dtype) {

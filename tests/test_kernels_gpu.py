@@ -662,6 +662,37 @@ DENSE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [(10, 4096, 6, True), (33, 1000, 3, False), (9, 4096, 2, True)])
+def test_qkv_projection_with_rope_token_on_the_lane_equals_the_tiled_kernel_bit_for_bit(K, case):
+    """fk_gemm_nt_rope routes wide bf16 projections at d = 384, head_dim 64 (M >= 32768, no bias) to the token-on-the-lane kernel
+    (qkv_rope_fused_kernel: rotation in registers, two waves per SIMD).  Its output must be the bits of the tiled kernel, which the same
+    entry point runs below the threshold: the reference is the same call on two ranges of whole samples — with and without the
+    pre-scaled query table, with a position offset, heads != 6 — and the rotation against the fp32 formula."""
+    B, T, H, prescaled = case
+    d, D = 384, 64
+    M, N = B * T, 3 * H * D
+    g = torch.Generator().manual_seed(B * T + H)
+    x = (torch.randn(M, d, generator=g) * 0.7).bfloat16().cuda()
+    w = (torch.randn(N, d, generator=g) / math.sqrt(d)).bfloat16().cuda()
+    Tc = T + 5
+    ang = torch.rand(Tc, D // 2, generator=g) * 6.28
+    both = torch.stack([torch.stack([ang.cos(), ang.sin()], -1), torch.stack([ang.cos(), ang.sin()], -1) * 0.1803]).contiguous().cuda()
+    tab, qtab = both[0], both[1]
+    kw = dict(q_cols=H * D, q_table=qtab) if prescaled else {}
+    out = K.gemm_nt_rope(x, w, None, tab, T, 5, D, 2 * H * D, **kw)
+    cut = (B // 2) * T
+    assert cut < 32768 and M - cut < 32768
+    ref = torch.cat([K.gemm_nt_rope(x[a:b], w, None, tab, T, 5, D, 2 * H * D, **kw) for a, b in ((0, cut), (cut, M))])
+    assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+    y = (x.float().cpu() @ w.float().cpu().t()).view(B, T, 3 * H, D // 2, 2)
+    cs = torch.stack([ang.cos(), ang.sin()], -1)[5:5 + T][None, :, None]
+    rot = torch.stack([y[..., 0] * cs[..., 0] - y[..., 1] * cs[..., 1], y[..., 0] * cs[..., 1] + y[..., 1] * cs[..., 0]], -1)
+    want = torch.cat([rot[:, :, :2 * H], y[:, :, 2 * H:]], 2)
+    if prescaled:
+        want[:, :, :H] *= 0.1803
+    torch.testing.assert_close(out.float().cpu().view(B, T, 3 * H, D // 2, 2), want, atol=4e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("case", [(32768, 64), (40_000 + 77, 1536), (33_000, 96)])
 def test_swiglu_up_projection_token_on_the_lane_equals_the_tiled_kernel_bit_for_bit(K, case):
     """fk_gemm_nt_swiglu routes wide bf16 MLPs at d = 384 (M >= 32768) to the token-on-the-lane kernel (mlp_up_fused_kernel: SwiGLU in registers,
