@@ -24,6 +24,11 @@ BOUNDS = {
     "gemm_nt_ring192_kernel": (256, 2, 0, 0),
     "gemm_nt_ring_kernel": (256, 2, 0, 0),
     "gemm_tn_big_kernel": (256, 2, 0, 0),
+    # the token-on-the-lane kernels of mlp_fused.hip (round 4): the backward chain keeps 192 accumulator registers in the AGPR half at one wave
+    # per SIMD (built without -amdgpu-mfma-vgpr-form), the two forward kernels run two waves per SIMD
+    "mlp_bwd_fused_kernel": (448, 1, 0, 0),
+    "mlp_up_fused_kernel": (256, 2, 0, 0),
+    "qkv_rope_fused_kernel": (256, 2, 0, 0),
 }
 
 
@@ -61,6 +66,16 @@ def test_compiled_kernel_stays_inside_its_register_and_spill_budget(table, frag)
             assert r.get("AGPRs", 0) >= 192
 
 
+def test_fused_mlp_backward_keeps_its_accumulators_in_the_agpr_half(table):
+    """fk_mlp_bwd_fused fits one wave per SIMD only because the 12 dx accumulator tiles live in AGPRs (its source is compiled without the
+    vgpr-form flag, build.flags_for): a build-flag or compiler change that moves them would spill or halve nothing silently — it would
+    simply not fit 256 VGPRs."""
+    hits = {n: r for n, r in table.items() if "mlp_bwd_fused_kernel" in n}
+    assert hits
+    for name, r in hits.items():
+        assert r.get("AGPRs", 0) >= 192 and r["VGPRs"] <= 256, (name, r)
+
+
 def test_lds_budgets_are_static_asserts():
     """160 KiB of LDS per CU: every large dynamic allocation is checked at compile time in the source itself"""
     from frankenstein_amd import build as B
@@ -69,6 +84,9 @@ def test_lds_budgets_are_static_asserts():
         assert f"static_assert({sym} <= 160 * 1024" in att, sym
     for sym in ("R2_LDS", "R192_LDS"):
         assert f"static_assert({sym} <= 160 * 1024" in gem, sym
+    mlp = (B.CSRC / "mlp_fused.hip").read_text()
+    for sym in ("MF_LDS", "MU_LDS", "QK_LDS"):
+        assert f"static_assert({sym} <= 160 * 1024" in mlp, sym
 
 
 def test_no_compiler_packed_fp32_with_half_swaps(table):
