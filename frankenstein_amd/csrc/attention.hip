@@ -90,6 +90,29 @@ FK_DEV int q_first(const AttnArgs& p, int b, int k) {
   return 0;
 }
 
+// FK_MASK_KEYPAD with nothing (or only a tail) padded: the number of leading entries of a validity row that are all non-zero, so the tiles
+// in front of the first padded position take the mask-free path (SimpleMAE passes a padding mask with every sample, models/mae.py:119-150,
+// and most rows of it are all-valid).  Wave-uniform; every lane of the wave calls it.  The 16 loads of a round are independent (one
+// exposed latency per 1024 entries), and the round loop ends at the first round that found a zero.
+FK_DEV int keypad_valid_prefix(const int* valid, int n, int lane) {
+  int first_bad = n;
+  for (int base = 0; base < n; base += 1024) {
+    int v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = base + 64 * i + lane;
+      v[i] = k < n ? valid[k] : 1;
+    }
+#pragma unroll
+    for (int i = 15; i >= 0; --i)
+      if (v[i] == 0) first_bad = base + 64 * i + lane;
+    if (__builtin_amdgcn_ballot_w64(first_bad != n) != 0) break;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) first_bad = min(first_bad, __shfl_xor(first_bad, off, 64));
+  return __builtin_amdgcn_readfirstlane(first_bad);
+}
+
 // ---- LDS fragment reads -------------------------------------------------------------------------
 // row-read: 8 contiguous head-dim elements (slots d = 16 s + 8 h + e) of image row `row`
 template <typename T> FK_DEV void frag_row(Frag<T>& f, const char* img, int stride, int row, int s, int h) {
@@ -271,6 +294,9 @@ FK_DEV unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
+#ifndef FK_KEYPAD_NO_FREE
+#define FK_KEYPAD_NO_FREE 0      // 1: a key-padding mask sends every tile down the per-element path (the form before round 4; A/B switch)
+#endif
 #ifndef FK_NT_STORES_ATTN
 #define FK_NT_STORES_ATTN 0      // 1: O / dQ / dK / dV rows stored non-temporal (written once; the launch keeps re-reading K / V or Q / dO out of L2)
 #endif
@@ -1290,6 +1316,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
   const bool q_ok = qrow < p.Nq;
   const bool prefix = p.mask_kind == FK_MASK_PREFIX, keypad = p.mask_kind == FK_MASK_KEYPAD;
   const int my_lim = ((prefix || keypad) && q_ok) ? p.limits[(int64_t)b * p.Nq + qrow] : 0;
+  // key padding: keys in front of the sample's first padded key need no predicate for a wave whose own 32 queries are all valid
+  int keypad_free = 0;
+  if (keypad && !FK_KEYPAD_NO_FREE) {
+    keypad_free = keypad_valid_prefix(p.qfirst + (int64_t)b * p.Nk, p.Nk, lane);
+    if (__builtin_amdgcn_ballot_w64(q_ok && my_lim == 0) != 0) keypad_free = 0;
+  }
 
   Frag<T> qf[4];
 #pragma unroll
@@ -1301,7 +1333,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_ps_kernel(AttnArgs p) {
   const int kv_end = keypad ? p.Nk : kv_limit(p, b, q_last);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
-  const int full_vis_end = kv_limit(p, b, wave_q_first);
+  const int full_vis_end = keypad ? keypad_free : kv_limit(p, b, wave_q_first);
 
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): from here on vmcnt counts only LDS-DMA instructions (see attn_fwd_kernel)
   // K and V tile t into ring slot sl: 16 one-KiB pieces per tile, NW <= 8: 16 / NW per wave; NW = 16: one piece per wave
@@ -1538,7 +1570,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_ps_kernel(AttnArgs p) 
   const int kv_end = keypad ? p.Nk : kv_limit(p, b, q_last);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   const int wave_q_first = min(q0 + wave * 32, p.Nq - 1);
-  const int full_vis_end = kv_limit(p, b, wave_q_first);
+  // key padding: tiles in front of the sample's first padded key take the mask-free path; a padded QUERY needs no predicate here, its
+  // statistic is +inf (the forward wrote LSE = +inf for a row that sees nothing), so P = exp2(S' - inf) = 0 either way
+  const int full_vis_end = keypad ? (FK_KEYPAD_NO_FREE ? 0 : keypad_valid_prefix(p.qfirst + (int64_t)b * p.Nk, p.Nk, lane)) : kv_limit(p, b, wave_q_first);
 
   DmaCursor<BKV, NW> kcur, vcur;
   static_assert(PCS == 4 || PCS == 2, "vmcnt immediates below");
@@ -2078,7 +2112,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_ps_kernel(AttnArgs p
   }
   const int qs = keypad ? 0 : (q_first(p, b, k0) / TQ) * TQ;
   const int ntiles = qs < p.Nq ? (p.Nq - qs + TQ - 1) / TQ : 0;
-  const int full_vis_q = q_first(p, b, min(k0 + wave * 32 + 31, p.Nk - 1));
+  // key padding: a wave whose 32 keys are all valid needs no predicate at all -- a padded query arrives with the staged statistic -inf
+  // (its LSE is +inf), exactly like the rows past Nq of the last tile, so its P is 0 on the mask-free path too
+  const bool keypad_keys_valid = !FK_KEYPAD_NO_FREE && __builtin_amdgcn_ballot_w64(k_ok && my_qf == 0) == 0;
+  const int full_vis_q = keypad ? (keypad_keys_valid ? 0 : 0x3fffffff) : q_first(p, b, min(k0 + wave * 32 + 31, p.Nk - 1));
   // Row statistics: the dQ kernel has left -LSE*log2(e) and -delta in the workspace exactly as the accumulators want them (rows padded to
   // the tile, -inf / 0 past Nq), so a tile's 64 + 64 floats travel by LDS-DMA like the tile itself: one 256-byte piece each, issued by
   // waves 0 and 1 (no statistics registers, no arithmetic, no LDS stores in this kernel any more).

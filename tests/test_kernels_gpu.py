@@ -372,6 +372,44 @@ def test_attention_prescaled_q_masks_from_tables(K):
         close(dv, vr.grad, dtype, atol16=4e-2)
 
 
+def test_attention_keypad_mask_free_tiles(K):
+    """A key-padding mask whose rows are (mostly) valid: the pre-scaled kernels send the tiles in front of a sample's first padded key
+    down the mask-free path (keypad_valid_prefix, attention.hip).  N > 1024 takes the scan's second round; sample 0 is all valid and must
+    give the bits of a launch without a mask, sample 1 is padded at the tail, sample 2 has holes (one in the first tile: nothing free)."""
+    B, H, N, D = 3, 2, 1100, 64
+    dtype = torch.bfloat16
+    cq = (1.0 / math.sqrt(D)) * 1.4426950408889634
+    valid = torch.ones(B, N, dtype=torch.bool)
+    valid[1, 1050:] = False
+    valid[2, 1030:1033] = False
+    valid[2, 20] = False
+    pad = (valid[:, None, :, None] & valid[:, None, None, :])
+    mask = K.Mask.from_padding(dev(valid), dev(valid))
+    qp = q(rnd(B, N, H, D, seed=1) * cq * 2.0, dtype)
+    kv, vv, do = (rnd(B, N, H, D, seed=s_) for s_ in (2, 3, 4))
+    qd, kd, vd, dod = dev(qp, dtype), dev(kv, dtype), dev(vv, dtype), dev(do, dtype)
+    o, lse = K.attn_fwd(qd, kd, vd, mask, q_prescaled=True)
+    qr = (qp / cq).requires_grad_(True)
+    kr, vr = (q(t_, dtype).requires_grad_(True) for t_ in (kv, vv))
+    oref = R.sdpa_zero_fully_masked(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), pad.expand(B, 1, N, N)).transpose(1, 2)
+    close(o, oref, dtype, atol16=2e-2)
+    assert bool(torch.isinf(lse.cpu()[(~valid)[:, None, :].expand(B, H, N)]).all())
+    (oref * q(do, dtype)).sum().backward()
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    K.attn_bwd(qd, kd, vd, o, dod, lse, dq, dk, dv, mask, q_prescaled=True)
+    close(dq, qr.grad, dtype, atol16=4e-2)
+    close(dk, kr.grad, dtype, atol16=4e-2)
+    close(dv, vr.grad, dtype, atol16=4e-2)
+    # sample 0 alone without a mask: the same bits
+    none = K.Mask(0, 0)
+    q0, k0, v0, g0 = (t_[:1].contiguous() for t_ in (qd, kd, vd, dod))
+    o0, lse0 = K.attn_fwd(q0, k0, v0, none, q_prescaled=True)
+    assert torch.equal(o0, o[:1]) and torch.equal(lse0, lse[:1])
+    dq0, dk0, dv0 = torch.empty_like(q0), torch.empty_like(k0), torch.empty_like(v0)
+    K.attn_bwd(q0, k0, v0, o0, g0, lse0, dq0, dk0, dv0, none, q_prescaled=True)
+    assert torch.equal(dq0, dq[:1]) and torch.equal(dk0, dk[:1]) and torch.equal(dv0, dv[:1])
+
+
 def test_attention_mask_offsets_and_spike(K):
     # sliced mask (t_q < t_k, models/brainformer.py:160-162) and a forced running-max jump (online softmax rescale)
     B, H, Nq, Nk, D = 1, 2, 40, 200, 32
