@@ -617,10 +617,18 @@ __global__ __launch_bounds__(MU_NW * 64, 2) void qkv_rope_fused_kernel(QkvArgs p
 }  // namespace
 
 // the token-on-the-lane form of fk_gemm_nt_rope (called from gemm.hip's entry point)
+// One 8-wave workgroup of 256 tokens per CU at a time: the launch runs in rounds of 256 workgroups, so its time is a step function of M
+// (150 / 293 / 460 us at <= 65 536 / 131 072 / 196 608 rows for the up-projection) where the tiled kernels' is linear.  Measured over
+// M = 19 200 ... 196 608 (tools/mlp_size_sweep.py, profiles/r04_mlp_size_sweep.txt): these kernels win wherever the last round is at least
+// ~40 % full, i.e. the grid fills >= 70 % of its rounds (49 152: 0.75 wins; 38 400 and 76 800: 0.59 lose by 5-12 %).
+static bool mu_grid_fills(int64_t M) {
+  const int64_t wg = fk_cdiv(M, MU_TOK), rounds = fk_cdiv(wg, 256);
+  return wg * 10 >= rounds * 256 * 7;
+}
 bool fk_qkv_rope_fused_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const void* bias, int64_t T, int64_t D, int64_t rot_cols,
                           int64_t q_cols, int dtype) {
   static const bool off = getenv("FK_QKV_FUSED") != nullptr && getenv("FK_QKV_FUSED")[0] == '0';
-  return !off && dtype == FK_BF16 && K == MF_D && D == 64 && N % 64 == 0 && rot_cols % 64 == 0 && q_cols % 64 == 0 && rot_cols <= N && !bias && M >= 32768 &&
+  return !off && dtype == FK_BF16 && K == MF_D && D == 64 && N % 64 == 0 && rot_cols % 64 == 0 && q_cols % 64 == 0 && rot_cols <= N && !bias && mu_grid_fills(M) &&
          M < (1LL << 31) && T > 0 && M % T == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && 64 * ldb * 2 < (1LL << 32);
 }
 int fk_qkv_rope_fused_launch(const void* A, int64_t lda, const void* W, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, const float* table,
@@ -637,7 +645,7 @@ int fk_qkv_rope_fused_launch(const void* A, int64_t lda, const void* W, int64_t 
 // the token-on-the-lane form of fk_gemm_nt_swiglu for the shapes it is built for (called from gemm.hip's entry point)
 bool fk_mlp_up_fused_ok(int64_t M, int64_t H, int64_t K, int64_t lda, int64_t ldb, int64_t ldh, int64_t ldg, int dtype) {
   static const bool off = getenv("FK_MLP_UP_FUSED") != nullptr && getenv("FK_MLP_UP_FUSED")[0] == '0';
-  return !off && dtype == FK_BF16 && K == MF_D && H % 32 == 0 && M >= 32768 && M < (1LL << 31) && lda % 8 == 0 && ldb % 8 == 0 && ldh % 8 == 0 && ldg % 8 == 0 &&
+  return !off && dtype == FK_BF16 && K == MF_D && H % 32 == 0 && mu_grid_fills(M) && M < (1LL << 31) && lda % 8 == 0 && ldb % 8 == 0 && ldh % 8 == 0 && ldg % 8 == 0 &&
          64 * ldb * 2 < (1LL << 32);
 }
 int fk_mlp_up_fused_launch(const void* A, int64_t lda, const void* W13, int64_t ldb, void* H13, int64_t ldh, void* G, int64_t ldg, int64_t M, int64_t H,

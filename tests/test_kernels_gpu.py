@@ -700,11 +700,11 @@ DENSE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", [(10, 4096, 6, True), (33, 1000, 3, False), (9, 4096, 2, True)])
+@pytest.mark.parametrize("case", [(12, 4096, 6, True), (49, 1000, 3, False), (13, 4096, 2, True)])
 def test_qkv_projection_with_rope_token_on_the_lane_equals_the_tiled_kernel_bit_for_bit(K, case):
-    """fk_gemm_nt_rope routes wide bf16 projections at d = 384, head_dim 64 (M >= 32768, no bias) to the token-on-the-lane kernel
-    (qkv_rope_fused_kernel: rotation in registers, two waves per SIMD).  Its output must be the bits of the tiled kernel, which the same
-    entry point runs below the threshold: the reference is the same call on two ranges of whole samples — with and without the
+    """fk_gemm_nt_rope routes wide bf16 projections at d = 384, head_dim 64 (no bias; row counts whose 256-token workgroups fill at least
+    70 % of their rounds of 256: from 45 825 rows on) to the token-on-the-lane kernel (qkv_rope_fused_kernel: rotation in registers, two
+    waves per SIMD).  Its output must be the bits of the tiled kernel, which the same entry point runs below the threshold: the reference is the same call on two ranges of whole samples — with and without the
     pre-scaled query table, with a position offset, heads != 6 — and the rotation against the fp32 formula."""
     B, T, H, prescaled = case
     d, D = 384, 64
@@ -719,7 +719,7 @@ def test_qkv_projection_with_rope_token_on_the_lane_equals_the_tiled_kernel_bit_
     kw = dict(q_cols=H * D, q_table=qtab) if prescaled else {}
     out = K.gemm_nt_rope(x, w, None, tab, T, 5, D, 2 * H * D, **kw)
     cut = (B // 2) * T
-    assert cut < 32768 and M - cut < 32768
+    assert M >= 45825 and cut < 45825 and M - cut < 45825
     ref = torch.cat([K.gemm_nt_rope(x[a:b], w, None, tab, T, 5, D, 2 * H * D, **kw) for a, b in ((0, cut), (cut, M))])
     assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
     y = (x.float().cpu() @ w.float().cpu().t()).view(B, T, 3 * H, D // 2, 2)
@@ -731,9 +731,9 @@ def test_qkv_projection_with_rope_token_on_the_lane_equals_the_tiled_kernel_bit_
     torch.testing.assert_close(out.float().cpu().view(B, T, 3 * H, D // 2, 2), want, atol=4e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("case", [(32768, 64), (40_000 + 77, 1536), (33_000, 96)])
+@pytest.mark.parametrize("case", [(49152, 64), (50_000 + 77, 1536), (49_000, 96)])
 def test_swiglu_up_projection_token_on_the_lane_equals_the_tiled_kernel_bit_for_bit(K, case):
-    """fk_gemm_nt_swiglu routes wide bf16 MLPs at d = 384 (M >= 32768) to the token-on-the-lane kernel (mlp_up_fused_kernel: SwiGLU in registers,
+    """fk_gemm_nt_swiglu routes wide bf16 MLPs at d = 384 (from 45 825 rows on, see mu_grid_fills in csrc/mlp_fused.hip) to the token-on-the-lane kernel (mlp_up_fused_kernel: SwiGLU in registers,
     two waves per SIMD): H13 and G must be the bits of the tiled kernel, which the same entry point runs below the threshold — rows are
     independent, so the reference is the same call on two row ranges under it — and both against the fp32 formula."""
     M, H = case
@@ -743,6 +743,7 @@ def test_swiglu_up_projection_token_on_the_lane_equals_the_tiled_kernel_bit_for_
     w13 = (torch.randn(2 * H, d, generator=g) / math.sqrt(d)).bfloat16().cuda()
     h13, gg = K.gemm_nt_swiglu(x, w13)
     cut = M // 2
+    assert M >= 45825 and M - cut < 45825
     ref = [K.gemm_nt_swiglu(x[a:b], w13) for a, b in ((0, cut), (cut, M))]
     h13_ref, g_ref = torch.cat([r[0] for r in ref]), torch.cat([r[1] for r in ref])
     assert torch.equal(h13, h13_ref), float((h13.float() - h13_ref.float()).abs().max())
