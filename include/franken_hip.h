@@ -94,7 +94,8 @@ int fk_colsum(const void* X, int64_t ld, float* out, int64_t rows, int64_t cols,
  * PREFIX (per-sample masks of sorted token subsets, MAE's get_sub_att_matrix models/brainformer.py:392-413):
  * visible(q,k) = k < limits[b,q] <=> q >= qfirst[b,k], int32 tables from fk_prefix_mask.
  * KEYPAD (padding mask of models/simple_mae:228-236,349-352): visible(q,k) = limits[b,q] != 0 && qfirst[b,k] != 0, i.e. the two
- * int32 tables are the query / key validity flags.  DENSE (any boolean mask: models/brainformer.py:160-168 passes whatever it is given):
+ * int32 tables are the query / key validity flags (FK_ATTN_Q_PRESCALED kernels: the tiles in front of a sample's first zero key flag
+ * take the mask-free path, same bits).  DENSE (any boolean mask: models/brainformer.py:160-168 passes whatever it is given):
  * `limits` points to uint8 [Bm, Hm, Nq, Nk] (non-zero = attend), mask_c = its batch stride and q_off its head stride in elements (0: one
  * mask for every sample / every head), k_off = 0, qfirst unused; every tile takes the per-element path of the generic kernels
  * (FK_ATTN_Q_PRESCALED is refused).
