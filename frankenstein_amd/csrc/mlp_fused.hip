@@ -14,6 +14,8 @@
 //     dh1, dh3        = SwiGLU derivative against the saved h13 rows (one 16-byte load per lane and k16-step), rounded to bf16:
 //                       the 8 values of a lane and step ARE the B fragment of the next product and the 16-byte dh13 store
 //     dx^T [384 x 32] += W13T_c [384 x 64] dh13^T                  48 MFMAs        (W13T_c: one 384-row image in LDS)
+// (Whole 128-token tiles take mlp_bwd_fused_asm_kernel further down: the same chain with its loop rotated by one product and the second
+// product's step as a generated instruction stream.)
 // The weight chunks (72 KB) arrive by LDS-DMA into a two-slot ring, chunk c + 1 requested when chunk c starts.  Products, operand
 // slots and summation order are those of the two GEMM kernels this replaces (k in ascending 16-blocks), so dh13 and dx come out
 // bit-identical to them (tests/test_kernels_gpu.py).
@@ -70,6 +72,19 @@ template <bool FAST_SIGMOID> FK_DEV float mf_sigmoid(float x) {
 FK_DEV void mf_dma(const void* base, unsigned voff, unsigned dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
 }
+
+#ifdef MF_STAMP
+// diagnostic build only (tools/build_variant.py mf_stamp mlp_fused.hip -DMF_STAMP; tools/stamp_mlp.py): cycles per segment of a chunk, summed over
+// waves.  s_memtime returns through lgkmcnt, so every stamp also drains the wave's LDS reads: coarse segments only.  Never in the product.
+__device__ unsigned long long mf_stamp_acc[16];
+#define MF_ST_DECL unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime(); const unsigned long long st_t0 = st_t;
+#define MF_ST(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+#define MF_ST_FLUSH if (lane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&mf_stamp_acc[i_], st_acc[i_]); atomicAdd(&mf_stamp_acc[15], __builtin_amdgcn_s_memtime() - st_t0); }
+#else
+#define MF_ST_DECL
+#define MF_ST(i)
+#define MF_ST_FLUSH
+#endif
 
 __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -303,6 +318,265 @@ __global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_kernel(MlpBwdArgs
       fk_st<true>(reinterpret_cast<bf16x8*>(p.dx + (int64_t)(m0 + r) * p.lddx + lane * 8), v);
     }
   }
+}
+
+
+// ================================================================================================================================
+// The same chain with its loop rotated by one product and the second product's step as a GENERATED instruction stream (round 4).
+//   A wave of mlp_bwd_fused_kernel is alone on its SIMD, so everything it issues shares one in-order stream, and the stamps
+//   (tools/stamp_mlp.py, profiles/r04_mf_stamps*.txt) fit one model: a gap behind an MFMA costs max(32, 8 + the issue time of what is
+//   placed in it) cycles.  The kernel above spends ~1900 cycles per chunk in the SwiGLU derivative with the matrix pipe idle (32 % of a
+//   wave's life); hipcc asked to interleave puts 8-9 VALU with two transcendentals into 32 of the 48 gaps of the second product (64
+//   cycles each) and leaves the rest at 32: no gain.  Here iteration c runs
+//        A(c): dg^T(c + 1) = W2T_{c+1} dy^T                      24 MFMAs (hipcc), the W13T(c + 1) requests behind its groups
+//        B(c): dx^T += W13T_c dh13^T(c)  BESIDE  the SwiGLU derivative of chunk c + 1, its dh13 tile round trip and stores, the W2T(c + 3)
+//              and h13 tile(c + 2) requests, the barrier         48 MFMAs: mlpb_step_asm (tools/gen/gen_mlpb_asm.py -> mlp_bwd_asm.inc),
+//              every gap filled to the same issue budget
+//   Same products and summation order, same arithmetic instruction for instruction: dh13 and dx are the bits of the kernel above.
+//   Whole 128-token tiles only (M % 128 == 0); the launcher keeps the kernel above for the rest (and FK_MLP_BWD_ASM=0 for everything).
+//
+//   Requests and waits (loads retire in order; N = the younger loads of this wave).  Issue order per wave:
+//        A(c): W13T(c + 1) [12]      B(c): W2T(c + 3) [6], dh13(c + 1) stores, h13 tile(c + 2) [4]      A(c + 1): W13T(c + 2) [12] ...
+//   * barrier B(c), in front of the last MFMA group of A(c): needs W13T(c) and this wave's tile(c + 1); the youngest loads are the 10
+//     W13T(c + 1) requests issued so far -> vmcnt(10); everything older has landed then, W2T(c + 2) included.  Behind it the W2T slot of
+//     chunk c + 1 is free (-> W2T(c + 3)), and the caller reads the stream's first fragments and its h13 pieces under the last MFMAs.
+//   * barrier A(c + 1), inside the stream in front of its last four MFMAs: nothing to wait for but this wave's own fragment reads; behind
+//     it the W13T slot of chunk c is free for the W13T(c + 2) requests of A(c + 1), whose first fragments the stream reads on its way out.
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+#ifndef FK_MLPB_INC
+#define FK_MLPB_INC "mlp_bwd_asm.inc"
+#endif
+#include FK_MLPB_INC
+
+__global__ __launch_bounds__(MF_NW * 64, 1) void mlp_bwd_fused_asm_kernel(MlpBwdArgs p) {
+  MF_ST_DECL
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using T = bf16_t;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = blockIdx.x * MF_TOK + wave * 32 + li;       // < M: whole tiles only
+  const int nchunks = p.H / 32, last = nchunks - 1;
+  auto cl = [&](int k) { return k < last ? k : last; };
+  const int row8 = lane >> 3, ch = lane & 7;
+  unsigned off2[MF_W2 / 1024 / MF_NW], off13[MF_W13 / 1024 / MF_NW];
+#pragma unroll
+  for (int j = 0; j < MF_W2 / 1024 / MF_NW; ++j) {
+    const int q = wave * (MF_W2 / 1024 / MF_NW) + j, s6 = q >> 2, r = (q & 3) * 8 + row8;
+    off2[j] = (unsigned)((r * (int)p.ldw2t + s6 * 64 + ((ch ^ ((r >> 1) & 7)) << 3)) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < MF_W13 / 1024 / MF_NW; ++j) {
+    const int r = (wave * (MF_W13 / 1024 / MF_NW) + j) * 8 + row8;
+    off13[j] = (unsigned)((r * (int)p.ldw13t + ((ch ^ ((r >> 1) & 7)) << 3)) * 2);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+  auto w2slot = [&](int i) -> char* { return smem + i * MF_W2; };
+  auto w13slot = [&](int i) -> char* { return smem + 2 * MF_W2 + i * MF_W13; };
+  auto dma_w2 = [&](int c, int slot, int j) __attribute__((always_inline)) {
+    mf_dma(p.w2t + (int64_t)c * 32 * p.ldw2t, off2[j], __builtin_amdgcn_readfirstlane(lds0 + slot * MF_W2 + wave * (MF_W2 / MF_NW)) + j * 1024);
+  };
+  auto dma_w13 = [&](int c, int slot, int j) __attribute__((always_inline)) {
+    mf_dma(p.w13t + (int64_t)c * 64, off13[j], __builtin_amdgcn_readfirstlane(lds0 + 2 * MF_W2 + slot * MF_W13 + wave * (MF_W13 / MF_NW)) + j * 1024);
+  };
+  char* hreg = smem + 2 * MF_SLOT + wave * MF_HREG;
+  const int m0w = blockIdx.x * MF_TOK + wave * 32;
+  const unsigned hreg_lds = __builtin_amdgcn_readfirstlane(lds0 + 2 * MF_SLOT + wave * MF_HREG);
+  // the stream's address operands: LDS byte addresses (adr) and global byte offsets (ofs); adr[0..3] and adr[12..15] follow the ring slots
+  u32x16 adr, ofs;
+  unsigned ax[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    ax[s] = (unsigned)nt_off(li, 2 * s + lh);
+    adr[4 + s] = hreg_lds + ax[s];                                          // AH: the lane's pieces of its tile
+    adr[8 + s] = hreg_lds + (unsigned)nt_off(s * 8 + row8, ch);             // AR: tile rows, eight lanes per row
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) ofs[j] = off2[j];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = j * 8 + row8;
+    ofs[6 + j] = (unsigned)(((int64_t)(m0w + r) * p.ldh + ((ch ^ ((r >> 1) & 7)) << 3)) * 2);     // HOFF: tile request pieces (swizzled source column)
+    ofs[10 + j] = (unsigned)(((int64_t)(m0w + r) * p.lddh + (ch << 3)) * 2);                       // VST: row stores (logical piece ch of row r)
+  }
+  ofs[14] = 0;
+  ofs[15] = 0;
+
+  // ---- prologue: W2T(0), W13T(0), W2T(1), tile(0); dy^T fragments; chunk 0's first product and SwiGLU derivative alone
+#pragma unroll
+  for (int j = 0; j < MF_W2 / 1024 / MF_NW; ++j) dma_w2(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < MF_W13 / 1024 / MF_NW; ++j) dma_w13(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < MF_W2 / 1024 / MF_NW; ++j) dma_w2(cl(1), 1, j);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mf_dma(p.h13, ofs[6 + j], hreg_lds + j * 1024);
+  Frag<T> dyf[MF_D / 16];
+  const T* dyrow = p.dy + (int64_t)m * p.lddy + 8 * lh;
+#pragma unroll
+  for (int t = 0; t < MF_D / 16; ++t) frag_load_contig<T>(dyf[t], dyrow + 16 * t);
+  f32x16 dx[MF_D / 32];
+#pragma unroll
+  for (int t = 0; t < MF_D / 32; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dx[t][r] = 0.0f;
+  MF_ST(4)                                                  // (stamp build: requests issued, dy fragments requested)
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  MF_ST(5)                                                  // (stamp build: the first wait)
+  Frag<T> fa[2][4];
+  f32x16 dg;
+  u32x16 fa0, bfc, bfn, hvv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dg[r] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) nt_frag<T>(fa[0][s], w2slot(0), li, s, lh);
+#pragma unroll
+  for (int s6 = 0; s6 < MF_KT; ++s6) {
+    if (s6 + 1 < MF_KT) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) nt_frag<T>(fa[(s6 + 1) & 1][s], w2slot(0) + (s6 + 1) * 32 * ROW_BYTES, li, s, lh);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mma32<T>(dg, fa[s6 & 1][s], dyf[s6 * 4 + s]);
+  }
+  {
+    bf16x8 rb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hreg + nt_off(li, 2 * s + lh));
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a1 = (float)hv[e], a3 = (float)hv[4 + e], g = dg[4 * s + e];
+        const float sg = mf_sigmoid<true>(a1), ds = g * sg;
+        o[e] = (T)(ds * a3 * (1.0f + a1 * (1.0f - sg)));
+        o[4 + e] = (T)(ds * a1);
+      }
+      *reinterpret_cast<bf16x8*>(hreg + nt_off(li, 2 * s + lh)) = o;
+      const u32x4v w = __builtin_bit_cast(u32x4v, o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bfc[4 * s + k] = w[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const bf16x8*>(hreg + nt_off(j * 8 + row8, ch));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fk_st<true>(reinterpret_cast<bf16x8*>(p.dh13 + (int64_t)(m0w + j * 8 + row8) * p.lddh + (ch << 3)), rb[j]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // everyone is done with W2T(0); this wave's tile rows are in registers
+#pragma unroll
+  for (int j = 0; j < MF_W2 / 1024 / MF_NW; ++j) dma_w2(cl(2), 0, j);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mf_dma(p.h13 + (int64_t)cl(1) * 64, ofs[6 + j], hreg_lds + j * 1024);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {                                       // A(0)'s first fragments: W2T(1) landed in front of the first barrier
+    const u32x4v w = *reinterpret_cast<const u32x4v*>(w2slot(1) + ax[s]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fa0[4 * s + k] = w[k];
+  }
+
+  MF_ST(0)                                                  // prologue
+  for (int c = 0; c < last; ++c) {
+    const char* w2img = w2slot((c + 1) & 1);
+    const char* w13img = w13slot(c & 1);
+    // ---- A(c): dg^T(c + 1), 24 MFMAs, fragments one group ahead; the last group behind barrier B(c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dg[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32x4v w = {fa0[4 * s], fa0[4 * s + 1], fa0[4 * s + 2], fa0[4 * s + 3]};
+      fa[0][s].v = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int s6 = 0; s6 < MF_KT; ++s6) {
+      if (s6 + 1 < MF_KT) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nt_frag<T>(fa[(s6 + 1) & 1][s], w2img + (s6 + 1) * 32 * ROW_BYTES, li, s, lh);
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        MF_ST(1)                                            // first product, groups 0-4
+        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier B(c)
+        MF_ST(2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const u32x4v w = *reinterpret_cast<const u32x4v*>(w13img + ax[s]);             // the stream's first fragments (feature tile 0) ...
+          const u32x4v h = *reinterpret_cast<const u32x4v*>(hreg + ax[s]);               // ... and this wave's h13 pieces of chunk c + 1
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { fa0[4 * s + k] = w[k]; hvv[4 * s + k] = h[k]; }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mma32<T>(dg, fa[s6 & 1][s], dyf[s6 * 4 + s]);
+      dma_w13(cl(c + 1), (c + 1) & 1, 2 * s6);
+      dma_w13(cl(c + 1), (c + 1) & 1, 2 * s6 + 1);
+      if (s6 + 1 < MF_KT) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    MF_ST(3)                                                // group 5
+    // ---- B(c): the generated step
+    const unsigned w13a = lds0 + 2 * MF_W2 + (c & 1) * MF_W13, w2a = lds0 + (c & 1) * MF_W2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      adr[s] = w13a + ax[s];
+      adr[12 + s] = w2a + ax[s];
+    }
+    mlpb_step_asm(dx, dg, fa0, bfc, bfn, hvv, adr, ofs, p.w2t + (int64_t)cl(c + 3) * 32 * p.ldw2t, p.h13 + (int64_t)cl(c + 2) * 64,
+                  p.dh13 + (int64_t)(c + 1) * 64, __builtin_amdgcn_readfirstlane(lds0 + ((c + 1) & 1) * MF_W2 + wave * (MF_W2 / MF_NW)), hreg_lds);
+    bfc = bfn;
+    MF_ST(6)                                                // the generated step (barrier A inside)
+  }
+  // ---- the last chunk's second product, alone
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // W13T(last) and the repeated requests of the tail have landed
+  MF_ST(7)
+  {
+    const char* w13img = w13slot(last & 1);
+    constexpr int NT12 = MF_D / 32;
+    Frag<T> bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32x4v w = {bfc[4 * s], bfc[4 * s + 1], bfc[4 * s + 2], bfc[4 * s + 3]};
+      bf[s].v = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) nt_frag<T>(fa[0][s], w13img, li, s, lh);
+#pragma unroll
+    for (int t = 0; t < NT12; ++t) {
+      if (t + 1 < NT12) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nt_frag<T>(fa[(t + 1) & 1][s], w13img, 32 * (t + 1) + li, s, lh);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mma32<T>(dx[t], fa[t & 1][s], bf[s]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  MF_ST(8)                                                  // the last chunk's second product
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave has its last fragments: the LDS is free for the dx staging
+
+  // ---- dx: accumulators -> bf16 rows staged in LDS -> 16-byte row stores (as in the kernel above)
+  char* stg = smem + wave * 32 * MF_ROWP;
+#pragma unroll
+  for (int t = 0; t < MF_D / 32; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (T)dx[t][4 * g + e];
+      *reinterpret_cast<bf16x4*>(stg + li * MF_ROWP + (32 * t + 8 * g + 4 * lh) * 2) = v;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane < MF_D / 8) {
+    for (int r = 0; r < 32; ++r) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + r * MF_ROWP + lane * 16);
+      fk_st<true>(reinterpret_cast<bf16x8*>(p.dx + (int64_t)(m0w + r) * p.lddx + lane * 8), v);
+    }
+  }
+  MF_ST(9)                                                  // dx epilogue
+  MF_ST_FLUSH
 }
 
 
@@ -658,6 +932,15 @@ int fk_mlp_up_fused_launch(const void* A, int64_t lda, const void* W13, int64_t 
   return FK_OK;
 }
 
+#ifdef MF_STAMP
+extern "C" int fk_debug_mf_stamps(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(mf_stamp_acc), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mf_stamp_acc), z, sizeof(z)); }
+  return 0;
+}
+#endif
+
 extern "C" int fk_mlp_bwd_fused(const void* dY, int64_t lddy, const void* W2T, int64_t ldw2t, const void* H13, int64_t ldh, const void* W13T,
                                 int64_t ldw13t, void* dH13, int64_t lddh, void* dX, int64_t lddx, int64_t M, int64_t H, int64_t D, int dtype,
                                 void* stream) {
@@ -674,9 +957,15 @@ extern "C" int fk_mlp_bwd_fused(const void* dY, int64_t lddy, const void* W2T, i
                "fk_mlp_bwd_fused: pointers must be 16-byte aligned");
   MlpBwdArgs a{(const bf16_t*)dY, (const bf16_t*)W2T, (const bf16_t*)H13, (const bf16_t*)W13T, (bf16_t*)dH13, (bf16_t*)dX,
                lddy, ldw2t, ldh, ldw13t, lddh, lddx, (int)M, (int)H};
-  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS) == hipSuccess);
+  static const bool asm_off = getenv("FK_MLP_BWD_ASM") != nullptr && getenv("FK_MLP_BWD_ASM")[0] == '0';
+  static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS) == hipSuccess) &&
+                     (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_asm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS) == hipSuccess);
   (void)once;
-  hipLaunchKernelGGL(mlp_bwd_fused_kernel, dim3((unsigned)fk_cdiv(M, MF_TOK)), dim3(MF_NW * 64), MF_LDS, (hipStream_t)stream, a);
+  // whole 128-token tiles, and the dh13 rows addressable with 32-bit byte offsets from a per-chunk scalar base: the generated-stream kernel
+  if (!asm_off && M % MF_TOK == 0 && M * lddh * 2 < (1LL << 32))
+    hipLaunchKernelGGL(mlp_bwd_fused_asm_kernel, dim3((unsigned)(M / MF_TOK)), dim3(MF_NW * 64), MF_LDS, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(mlp_bwd_fused_kernel, dim3((unsigned)fk_cdiv(M, MF_TOK)), dim3(MF_NW * 64), MF_LDS, (hipStream_t)stream, a);
   FK_CHECK_LAUNCH("fk_mlp_bwd_fused");
   return FK_OK;
 }

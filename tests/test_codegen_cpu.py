@@ -27,6 +27,7 @@ BOUNDS = {
     # the token-on-the-lane kernels of mlp_fused.hip (round 4): the backward chain keeps 192 accumulator registers in the AGPR half at one wave
     # per SIMD (built without -amdgpu-mfma-vgpr-form), the two forward kernels run two waves per SIMD
     "mlp_bwd_fused_kernel": (448, 1, 0, 0),
+    "mlp_bwd_fused_asm_kernel": (464, 1, 0, 0),           # + the generated step's pinned operand tuples: 256 VGPRs + 208 AGPRs
     "mlp_up_fused_kernel": (256, 2, 0, 0),
     "qkv_rope_fused_kernel": (256, 2, 0, 0),
 }
@@ -55,6 +56,19 @@ def test_compiled_kernel_stays_inside_its_register_and_spill_budget(table, frag)
         assert hot is None or hot[3] == 0, f"{name}: scratch traffic in the hot loop {hot}"
         if "asm_kernel" in frag:
             assert hot is not None and hot[2] >= 24, (name, hot)          # the generated tile step(s) are in that loop
+        if "mlp_bwd_fused_asm" in frag:
+            # the generated step pins dx to a[0:191]: no compiler register traffic with the accumulator half anywhere in the chunk loop
+            lines = open(r["_asm"]).read().splitlines()
+            start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
+            body, inside = [], False
+            for l in lines[start + hot[0]:start + hot[1]]:
+                if "#ASMSTART" in l:
+                    inside = True
+                elif "#ASMEND" in l:
+                    inside = False
+                elif not inside:
+                    body.append(l)
+            assert not [l for l in body if "v_accvgpr" in l], "compiler moves into / out of the accumulator half inside the chunk loop"
         if "dkdvw" in frag:
             # the wide stream carries values from step to step in pinned registers and keeps accumulators / fragments in the accumulator
             # half: no register traffic (v_mov / v_accvgpr) may appear between the steps of its loop

@@ -329,9 +329,13 @@ def test_bench_self_launch_dry_run_world2():
         assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "AssertionError" not in r.stderr
 
 
-@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd", "dq16", "dkdvw"])
+STREAMS = {"dkdv": "attn_dkdv_asm.inc", "dq": "attn_dq_asm.inc", "fwd": "attn_fwd_asm.inc", "dq16": "attn_dq16_asm.inc", "dkdvw": "attn_dkdvw_asm.inc",
+           "mlpb": "mlp_bwd_asm.inc"}
+
+
+@pytest.mark.parametrize("gen", sorted(STREAMS))
 def test_generated_streams_are_current(tmp_path, gen):
-    """frankenstein_amd/csrc/attn_*_asm.inc are build inputs that are committed: the generators (tools/gen) reproduce them byte for byte."""
+    """frankenstein_amd/csrc/attn_*_asm.inc and mlp_bwd_asm.inc are build inputs that are committed: the generators (tools/gen) reproduce them byte for byte."""
     import subprocess
     import sys
     from pathlib import Path
@@ -339,7 +343,7 @@ def test_generated_streams_are_current(tmp_path, gen):
     out = tmp_path / "gen.inc"
     env = {k: v for k, v in os.environ.items() if not k.startswith("FK_GEN_")}
     subprocess.run([sys.executable, str(root / "tools" / "gen" / f"gen_{gen}_asm.py"), str(out)], check=True, env=env, capture_output=True)
-    assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / f"attn_{gen}_asm.inc").read_bytes()
+    assert out.read_bytes() == (root / "frankenstein_amd" / "csrc" / STREAMS[gen]).read_bytes()
 
 
 def _verify_stream():
@@ -351,15 +355,17 @@ def _verify_stream():
     return m
 
 
-@pytest.mark.parametrize("gen", ["dkdv", "dq", "fwd", "dq16", "dkdvw"])
+@pytest.mark.parametrize("gen", sorted(STREAMS))
 def test_generated_streams_keep_their_hazard_rules(gen):
     """every asm block of the committed streams replayed against the rules the generators promise (counted LDS waits, VALU -> consumer
     distance, MFMA result -> VALU distance, fragment overwrite behind its MFMA, M0 -> LDS-DMA distance): tools/gen/verify_stream.py"""
     from pathlib import Path
     vs = _verify_stream()
-    text = (Path(__file__).resolve().parents[1] / "frankenstein_amd" / "csrc" / f"attn_{gen}_asm.inc").read_text()
+    text = (Path(__file__).resolve().parents[1] / "frankenstein_amd" / "csrc" / STREAMS[gen]).read_text()
     blocks = list(vs.blocks(text))
-    assert len(blocks) >= 3
+    assert len(blocks) >= (1 if gen == "mlpb" else 3)
+    if gen == "mlpb":
+        assert sum(i.startswith("v_mfma") for i in blocks[0][1]) == 48
     errs = [e for name, ins in blocks for e in vs.check_block(name, ins)]
     assert not errs, errs[:5]
 
@@ -384,6 +390,13 @@ def test_stream_verifier_sees_violations():
     assert any("M0 written" in e for e in vs.check_block("b", m0_late))
     unwaited = ok + ["ds_read_b128 v[100:103], %[a] offset:0"]
     assert any("not waited for" in e for e in vs.check_block("b", unwaited))
+    # the fused MLP backward's stream also writes LDS and stores rows: an LDS write counts in lgkmcnt, neither may read a pending register
+    tile = ["ds_read_b128 v[100:103], %[a] offset:0", "v_cvt_pk_bf16_f32 v110, v111, v112", "s_nop 0", "ds_write_b128 v120, v[108:111]", "s_waitcnt lgkmcnt(0)",
+            "global_store_dwordx4 v121, v[100:103], %[g] nt"]
+    assert vs.check_block("ok2", tile) == []
+    assert any("may still be outstanding" in e for e in vs.check_block("b", tile[:4] + [tile[5], tile[4]]))
+    assert any("right in front" in e for e in vs.check_block("b", tile[:2] + tile[3:]))
+    assert any("not waited for" in e for e in vs.check_block("b", tile[:4]))
 
 
 def test_dense_mask_tables_follow_the_reference_slice_and_broadcast():

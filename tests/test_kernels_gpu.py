@@ -754,12 +754,14 @@ def test_swiglu_up_projection_token_on_the_lane_equals_the_tiled_kernel_bit_for_
     torch.testing.assert_close(gg.float().cpu(), (torch.nn.functional.silu(hh[:, :, 0]) * hh[:, :, 1]).reshape(M, H), atol=3e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("case", [(256, 64), (1000, 96), (4096 + 37, 1536), (128, 32)])
+@pytest.mark.parametrize("case", [(256, 64), (1000, 96), (4096 + 37, 1536), (128, 32), (4096, 1536), (1024, 96), (384, 160), (33 * 1024, 1536)])
 def test_mlp_backward_fused_equals_the_two_gemm_kernels_bit_for_bit(K, case):
     """fk_mlp_bwd_fused (the SwiGLU MLP's data-gradient chain in one launch, token on the lane, dh13 handed from the first product to the
     second in registers) against the two launches it replaces — fk_gemm_nt_dswiglu, then fk_gemm_nt on the dh13 it wrote: same products,
     operand slots and summation order, so dh13 AND dx must be identical bits (ragged row counts: the last workgroup and wave are partial),
-    and both against the fp32 oracle formula."""
+    and both against the fp32 oracle formula.  Row counts that are whole 128-token tiles take mlp_bwd_fused_asm_kernel (the second
+    product's step as a generated instruction stream with the next chunk's SwiGLU derivative in its gaps): 1, 2, 3, 5 and 48 chunks, more
+    workgroups than CUs."""
     M, H = case
     d = 384
     g = torch.Generator().manual_seed(M + H)

@@ -8,6 +8,8 @@
      (two for the 8-pass 32x32x16, three for the 4-pass 16x16x32).
   4. A ds_read overwrites a register only after the last MFMA that read it as an operand AND one more MFMA have been issued.
   5. M0 is written at least one instruction ahead of the LDS-DMA request that uses it.
+  6. (mlp_bwd_asm.inc) ds_write counts in lgkmcnt like a read; neither it nor a global_store reads a register of an outstanding ds_read, nor
+     the VALU result of the instruction right in front of it.
 Only the hard-coded temporaries (vNNN) are tracked; named operands (%[..]) are hipcc's registers and never alias them.
 usage: verify_stream.py file.inc [...]   -> exit code 1 and a list of violations on failure
 """
@@ -61,6 +63,23 @@ def check_block(name, ins):
         if op.startswith("global_load_lds"):
             if m0_at is None or i - m0_at < 2:
                 errs.append(f"{name}[{i}] {s}: M0 written {0 if m0_at is None else i - m0_at} instructions earlier")
+            last_valu = None
+            continue
+        if op.startswith("ds_write"):                 # an LDS operation like a read (lgkmcnt counts it), without a destination register
+            src = [r for o in ops for r in regs(o)]
+            for (j, d) in lds_q:
+                if d & set(src):
+                    errs.append(f"{name}[{i}] {s}: reads v{sorted(d & set(src))[0]} of the ds_read at [{j}] that may still be outstanding")
+            if last_valu and set(last_valu[1]) & set(src):
+                errs.append(f"{name}[{i}] {s}: stores the VALU result of the instruction right in front of it")
+            lds_q.append((i, set()))
+            last_valu = None
+            continue
+        if op.startswith("global_store"):
+            src = [r for o in ops for r in regs(o)]
+            for (j, d) in lds_q:
+                if d & set(src):
+                    errs.append(f"{name}[{i}] {s}: stores v{sorted(d & set(src))[0]} of the ds_read at [{j}] that may still be outstanding")
             last_valu = None
             continue
         dst = regs(ops[0]) if ops else []
