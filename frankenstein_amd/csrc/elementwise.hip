@@ -319,6 +319,53 @@ __global__ void gather_rows_kernel(const TS* src, int64_t src_bs, const int64_t*
     else dst[(int64_t)b * dst_bs + (int64_t)k * W + c] = from_f32<TD>(to_f32<TS>(src[(int64_t)b * src_bs + j * W + c]));
   }
 }
+// The same for rows of W % 8 == 0 elements with 16-byte-aligned rows: a lane moves 8 elements (one 16-byte load on the narrower side), a
+// wave covers 64 / (W / 8) rows per pass (W = 384: one row on 48 lanes), the row index is read once per row and the row arithmetic is
+// 32-bit.  The element-wise kernel above spends a 64-bit division and modulo per ELEMENT: SimpleMAE's seven token gathers of 38 400 x 384
+// took 82 us each at B = 256 (0.7 TB/s); same values (a copy, or the same conversion).
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void gather_rows_vec_kernel(const TS* src, int64_t src_bs, const int64_t* idx, int64_t idx_mod, TD* dst, int B, int n,
+                                                              int W, int scatter, int64_t dst_bs) {
+  const int cpr = W >> 3;                                   // 8-element chunks per row
+  const int lane = threadIdx.x & 63;
+  const int rpw = cpr >= 64 ? 1 : 64 / cpr;                 // rows per wave and pass
+  const int sub = cpr >= 64 ? 0 : lane / cpr;               // which of them this lane works on
+  const int c0 = cpr >= 64 ? lane : lane - sub * cpr;
+  if (sub >= rpw) return;
+  const unsigned rows = (unsigned)B * (unsigned)n;
+  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (unsigned r = wave * rpw + sub; r < rows; r += nwaves * rpw) {
+    const unsigned b = r / (unsigned)n, k = r - b * (unsigned)n;
+    int64_t j = idx[r];
+    if (idx_mod > 0) j %= idx_mod;
+    const TS* sp = src + (int64_t)b * src_bs + (scatter ? (int64_t)k : j) * W;
+    TD* dp = dst + (int64_t)b * dst_bs + (scatter ? j : (int64_t)k) * W;
+    for (int c = c0; c < cpr; c += 64) {
+      float v[8];
+      if constexpr (sizeof(TS) == 2) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(sp + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+      } else {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(sp + 8 * c), x1 = *reinterpret_cast<const f32x4*>(sp + 8 * c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+      }
+      if constexpr (sizeof(TD) == 2) {
+        bf16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = from_f32<TD>(v[e]);
+        *reinterpret_cast<bf16x8*>(dp + 8 * c) = y;
+      } else {
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y0[e] = v[e]; y1[e] = v[4 + e]; }
+        *reinterpret_cast<f32x4*>(dp + 8 * c) = y0;
+        *reinterpret_cast<f32x4*>(dp + 8 * c + 4) = y1;
+      }
+    }
+  }
+}
 // table[idx[b, i] % idx_mod, :] += src[b, i, :]   (fp32 atomics; gradient of a broadcast-table gather)
 template <typename TS>
 __global__ void scatter_add_rows_kernel(const TS* src, const int64_t* idx, int64_t idx_mod, float* table, int64_t rows, int W) {
@@ -591,7 +638,17 @@ int fk_gather_rows(const void* src, int64_t src_bs, int src_dtype, const int64_t
   FK_CHECK_ARG(src && idx && dst && B > 0 && n > 0 && W > 0 && B * n < (1LL << 31) && W < (1LL << 31), "fk_gather_rows: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   dim3 g(grid_for(B * n * W, 16384)), b(TPB);
-#define FK_GR(TS, TD) hipLaunchKernelGGL((gather_rows_kernel<TS, TD>), g, b, 0, s, (const TS*)src, src_bs, idx, idx_mod, (TD*)dst, (int)B, (int)n, (int)W, scatter, dst_bs)
+  // whole 8-element chunks, rows and batches on 16-byte boundaries on both sides: the vector kernel
+  const bool vec = W % 8 == 0 && src_bs % 8 == 0 && dst_bs % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  if (vec) {
+    const int64_t cpr = W / 8, rpw = cpr >= 64 ? 1 : 64 / cpr, waves = fk_cdiv(B * n, rpw);
+    g = dim3((unsigned)(fk_cdiv(waves, TPB / 64) < 4096 ? fk_cdiv(waves, TPB / 64) : 4096));
+  }
+#define FK_GR(TS, TD)                                                                                                                              \
+  do {                                                                                                                                             \
+    if (vec) hipLaunchKernelGGL((gather_rows_vec_kernel<TS, TD>), g, b, 0, s, (const TS*)src, src_bs, idx, idx_mod, (TD*)dst, (int)B, (int)n, (int)W, scatter, dst_bs); \
+    else hipLaunchKernelGGL((gather_rows_kernel<TS, TD>), g, b, 0, s, (const TS*)src, src_bs, idx, idx_mod, (TD*)dst, (int)B, (int)n, (int)W, scatter, dst_bs); \
+  } while (0)
   if (src_dtype == FK_F32 && dst_dtype == FK_F32) FK_GR(float, float);
   else if (src_dtype == FK_F32) FK_GR(float, bf16_t);
   else if (dst_dtype == FK_F32) FK_GR(bf16_t, float);

@@ -645,9 +645,13 @@ def test_fused_rope_projection_and_backward(K, dtype):
     close(d2, d1.float().cpu(), dtype, atol32=1e-6, atol16=3e-2)
 
 
+@pytest.mark.parametrize("shape", [(3, 40, 11, 24), (5, 300, 150, 384), (2, 64, 33, 256), (2, 50, 20, 520), (3, 40, 11, 20)])
 @pytest.mark.parametrize("dtype", DT)
-def test_gather_scatter_rows(K, dtype):
-    B, N, n, W = 3, 40, 11, 24
+def test_gather_scatter_rows(K, dtype, shape):
+    """fk_gather_rows / fk_scatter_add_rows (MAE token subsets, models/brainformer.py:429-472, models/simple_mae).  Rows of whole 8-element
+    chunks take the vector kernel (16 bytes per lane, one index load per row: 24 = three chunks and 21 rows per wave, 384 = one row on 48
+    lanes, 256 = two rows per wave, 520 = more chunks than lanes), 20 stays on the element-wise one."""
+    B, N, n, W = shape
     src = rnd(B, N, W, seed=1)
     idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(i))[:n].sort()[0] for i in range(B)])
     g = K.gather_rows(dev(src, dtype), dev(idx))
