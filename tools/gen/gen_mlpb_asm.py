@@ -47,6 +47,7 @@ NT, NK = 12, 4
 BUDGET = int(os.environ.get("FK_GEN_MLPB_BUDGET", "7"))
 LDS_PER_GAP = int(os.environ.get("FK_GEN_MLPB_LDS", "2"))
 W2_GAPS = [int(x) for x in os.environ.get("FK_GEN_MLPB_W2_GAPS", "3,9,15,21,27,33").split(",")]
+WAIT_PER_TILE = int(os.environ.get("FK_GEN_MLPB_WAIT_PER_TILE", "1"))
 BARRIER_AT = 45                       # in front of MFMA 45 (feature tile 11): every W13T fragment of this wave is in registers
 
 
@@ -152,9 +153,13 @@ def gen():
             S.need([q for q in S.queue if q[0] == "f"])
             S.emit("s_barrier")
         if t >= 1:
-            if (t, s) in frag_reads:                                    # not scheduled in time: now
-                S.lds(("f", t, s), frag_reads.pop((t, s))[0])
-            S.need([("f", t, s)])
+            # ONE wait per feature tile, in front of its first MFMA, for the tile's last fragment (LDS operations return in order, and the
+            # fragments are requested seven gaps ahead): a wait per MFMA costs the lone wave an issue slot each
+            for ss in range(NK if WAIT_PER_TILE and s == 0 else 1):
+                key = (t, ss if WAIT_PER_TILE and s == 0 else s)
+                if key in frag_reads:                                   # not scheduled in time: now
+                    S.lds(("f",) + key, frag_reads.pop(key)[0])
+            S.need([("f", t, NK - 1)] if WAIT_PER_TILE and s == 0 else [("f", t, s)])
         S.emit(f"v_mfma_f32_32x32x16_bf16 {ar(16 * t, 16)}, {vr(frag(t, s), 4)}, {vr(BFC + 4 * s, 4)}, {ar(16 * t, 16)}", ("m", g))
         units = BUDGET
         # 1. the fragment reads that come due first
